@@ -1,0 +1,64 @@
+"""ctypes binding of the C ABI declared in include/cvpce_amd.h.
+
+The HIP library is the product: there is NO CPU fallback.  Importing this
+module without a built `libcvpce_hip.so` raises immediately (build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C cvpce_amd/csrc`).
+"""
+import ctypes
+import os
+from ctypes import c_int, c_float, c_void_p, c_size_t, c_longlong, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcvpce_hip.so')
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise HipLibraryMissing(
+        f'{LIB_PATH} not found: the cvpce_amd hot path has no CPU fallback. '
+        'Build the HIP library first (python -c "import __graft_entry__ as g; g.build()").')
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_vp = c_void_p
+_fp = c_void_p   # float* passed as raw device address
+_ip = c_void_p
+
+SIGNATURES = {
+    'cvpce_conv2d_nhwc_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 19 + [_vp]),
+    'cvpce_maxpool2d_nhwc_bf16': (c_int, [_vp, _vp] + [c_int] * 9 + [_vp]),
+    'cvpce_relu_bf16': (c_int, [_vp, _vp, c_longlong, _vp]),
+    'cvpce_global_max_nhwc_bf16': (c_int, [_vp, _fp, c_int, c_int, c_int, c_int, c_int, _vp]),
+    'cvpce_l2_normalize_f32': (c_int, [_fp, _fp, _vp, c_int, c_int, c_float, _vp]),
+    'cvpce_gln_transform': (c_int, [_fp, _vp] + [c_int] * 6 + [POINTER(c_float), POINTER(c_float), _vp]),
+    'cvpce_crop_resize': (c_int, [_fp, _fp, _ip, c_int, _vp, c_int, c_int, c_int, c_int,
+                                  POINTER(c_float), POINTER(c_float), _vp]),
+    'cvpce_pack_embed_input': (c_int, [_fp, _vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _vp]),
+    'cvpce_detect_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cvpce_detect_postprocess': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), POINTER(c_int),
+                                         POINTER(c_int), POINTER(c_int), _fp, _ip, _fp,
+                                         c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_float,
+                                         _vp, c_size_t, _fp, _fp, _vp, _ip, _ip, _vp]),
+    'cvpce_row_norms': (c_int, [_vp, _fp, c_int, c_int, c_int, c_float, _vp]),
+    'cvpce_match_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cvpce_match_topk': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _vp, c_size_t, _vp, _fp, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+_ERR = {1: 'bad argument', 2: 'kernel launch failure'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed: {_ERR.get(rc, rc)}')
+
+
+def float3(vals):
+    return (c_float * 3)(*[float(v) for v in vals])

@@ -1,0 +1,39 @@
+// Shared device helpers for the cvpce_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define CVPCE_OK 0
+#define CVPCE_ERR_ARG 1
+#define CVPCE_ERR_LAUNCH 2
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+
+// Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD
+// (round-robin dispatch), so give each XCD label a contiguous chunk of the
+// logical tile space -> neighbouring tiles hit the same per-XCD L2.  Speed
+// only; correctness never depends on placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < 2 * nx) return bid;
+    int q = nwg / nx, r = nwg % nx;
+    int xcd = bid % nx, idx = bid / nx;
+    int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+static inline int cvpce_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CVPCE_OK : CVPCE_ERR_LAUNCH;
+}

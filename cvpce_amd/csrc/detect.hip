@@ -1,0 +1,439 @@
+// RetinaNet post-processing on the GPU, torchvision 0.9
+// semantics (Appendix A: postprocess_detections, BoxCoder.decode_single,
+// clip_boxes_to_image, batched_nms/nms, transform.postprocess), reached from
+// /root/reference/cvpce/models/proposals.py:176-181 via RetinaNet.forward and
+// consumed at /root/reference/cvpce/production.py:13-15.
+//
+//   decode_topk  one 1024-thread workgroup per (level, image): sigmoid +
+//                score threshold, exact top-k by 4-pass LDS radix select,
+//                LDS bitonic sort of the <=1024 survivors, anchor synthesis +
+//                box decode + clip.
+//   nms_sort     one workgroup per image: merge the levels, LDS bitonic sort
+//                of <=8192 candidates by (logit desc, position asc).
+//   nms_mask     64x64 IoU bit-matrix tiles (upper triangle), one wave per tile.
+//   nms_scan     one wave per image: 64-box chunks; in-chunk dependencies via
+//                v_readlane on the diagonal words, cross-chunk via OR of the
+//                kept rows; early exit at detections_per_img; rescale to the
+//                original image, count the score > confidence prefix.
+//
+// Ordering rule: the reference sorts on sigmoid scores with an unstable sort,
+// leaving ties unspecified.  Here every ordering uses the fp32 *logit* (a
+// monotone refinement of the score order) and then the lower index.
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+#include <math.h>
+#pragma clang fp contract(off)
+
+#define MAX_LEVELS 8
+#define SORT_CAP 8192
+
+struct DecodeArgs {
+    const float* logits[MAX_LEVELS];   // [N][gh*gw*A*K]
+    const float* regs[MAX_LEVELS];     // [N][gh*gw*A][4]
+    int gh[MAX_LEVELS], gw[MAX_LEVELS], sh[MAX_LEVELS], sw[MAX_LEVELS];
+    const float* base_anchors;         // [L][A][4]
+    const int* image_hw;               // [N][2] resized (unpadded) sizes
+    int L, N, A, K, topk;
+    float score_thresh, xform_clip;
+    float* cand_boxes;                 // [N][L*topk][4]
+    float* cand_scores;                // [N][L*topk]
+    float* cand_logits;                // [N][L*topk]
+    int* cand_labels;                  // [N][L*topk]
+    int* cand_count;                   // [N][L]
+};
+
+__device__ __forceinline__ unsigned ordered_key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
+
+// descending bitonic sort of n (power of two) 64-bit keys in LDS by `nthreads` threads
+__device__ void bitonic_sort_desc(unsigned long long* s, int n, int tid, int nthreads) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += nthreads) {
+                int p = i ^ j;
+                if (p > i) {
+                    unsigned long long a = s[i], b = s[p];
+                    bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { s[i] = b; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
+    __shared__ unsigned long long sel[1024];
+    __shared__ int hist[256];
+    __shared__ int wtot[16];
+    __shared__ int s_cnt, s_prefix, s_need, s_nsel, s_eqbase;
+
+    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int gh = a.gh[level], gw = a.gw[level];
+    const int n = gh * gw * a.A * a.K;
+    const float* lg = a.logits[level] + (size_t)img * n;
+    const float* rg = a.regs[level] + (size_t)img * (size_t)(gh * gw * a.A) * 4;
+
+    if (tid == 0) { s_cnt = 0; s_nsel = 0; s_eqbase = 0; }
+    sel[tid] = 0ull;
+    __syncthreads();
+    // count candidates above the score threshold
+    int local = 0;
+    for (int i = tid; i < n; i += 1024) local += (sigmoidf_ref(lg[i]) > a.score_thresh) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+    if ((tid & 63) == 0) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    const int cnt = s_cnt;
+    const int k = cnt < a.topk ? cnt : a.topk;
+
+    unsigned T = 0;       // key of the k-th largest candidate
+    int need_eq = 0;      // how many candidates with key == T are taken (lowest index first)
+    if (cnt > k) {
+        unsigned prefix = 0, mask = 0;
+        int need = k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                float l = lg[i];
+                if (sigmoidf_ref(l) > a.score_thresh) {
+                    unsigned key = ordered_key(l);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, b = 255;
+                for (; b > 0; --b) {
+                    if (cum + hist[b] >= need) break;
+                    cum += hist[b];
+                }
+                s_prefix = (int)(prefix | ((unsigned)b << shift));
+                s_need = need - cum;
+            }
+            __syncthreads();
+            prefix = (unsigned)s_prefix;
+            need = s_need;
+            mask |= 0xFFu << shift;
+            __syncthreads();
+        }
+        T = prefix;
+        need_eq = need;
+    }
+    // ordered compaction: key > T always; key == T for the first need_eq in index order
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        bool valid = false, gt = false, eq = false;
+        unsigned key = 0;
+        if (i < n) {
+            float l = lg[i];
+            valid = sigmoidf_ref(l) > a.score_thresh;
+            key = ordered_key(l);
+            if (cnt > k) { gt = valid && key > T; eq = valid && key == T; }
+            else gt = valid;
+        }
+        bool take = gt;
+        if (cnt > k) {
+            unsigned long long bal = __ballot(eq);
+            int lane = tid & 63, w = tid >> 6;
+            int pre = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wtot[w] = __popcll(bal);
+            __syncthreads();
+            int before = s_eqbase;
+            for (int ww = 0; ww < w; ++ww) before += wtot[ww];
+            if (eq && before + pre < need_eq) take = true;
+            __syncthreads();
+            if (tid == 0) {
+                int t = 0;
+                for (int ww = 0; ww < 16; ++ww) t += wtot[ww];
+                s_eqbase += t;
+            }
+            __syncthreads();
+        }
+        if (take) {
+            int pos = atomicAdd(&s_nsel, 1);
+            if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    bitonic_sort_desc(sel, 1024, tid, 1024);
+
+    const int slot = a.L * a.topk;
+    if (tid == 0) a.cand_count[img * a.L + level] = k;
+    if (tid < k) {
+        const unsigned long long comp = sel[tid];
+        const int idx = (int)(0xFFFFFFFFu - (unsigned)(comp & 0xFFFFFFFFull));
+        const float l = lg[idx];
+        const int aidx = idx / a.K, label = idx - aidx * a.K;
+        const int cell = aidx / a.A, an = aidx - cell * a.A;
+        const int y = cell / gw, x = cell - y * gw;
+        const float shx = (float)x * (float)a.sw[level], shy = (float)y * (float)a.sh[level];
+        const float* ba = a.base_anchors + ((size_t)level * a.A + an) * 4;
+        const float ax1 = shx + ba[0], ay1 = shy + ba[1], ax2 = shx + ba[2], ay2 = shy + ba[3];
+        const float w = ax2 - ax1, h = ay2 - ay1;
+        const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+        const float4 r = *reinterpret_cast<const float4*>(rg + (size_t)aidx * 4);
+        const float dw = fminf(r.z, a.xform_clip), dh = fminf(r.w, a.xform_clip);
+        const float pcx = r.x * w + cx, pcy = r.y * h + cy;
+        const float pw = expf(dw) * w, ph = expf(dh) * h;
+        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+        const float ih = (float)a.image_hw[img * 2 + 0], iw = (float)a.image_hw[img * 2 + 1];
+        x1 = fminf(fmaxf(x1, 0.f), iw); x2 = fminf(fmaxf(x2, 0.f), iw);
+        y1 = fminf(fmaxf(y1, 0.f), ih); y2 = fminf(fmaxf(y2, 0.f), ih);
+        const size_t o = (size_t)img * slot + (size_t)level * a.topk + tid;
+        *reinterpret_cast<float4*>(a.cand_boxes + o * 4) = make_float4(x1, y1, x2, y2);
+        a.cand_scores[o] = sigmoidf_ref(l);
+        a.cand_logits[o] = l;
+        a.cand_labels[o] = label;
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct NmsArgs {
+    const float* cand_boxes; const float* cand_scores; const float* cand_logits; const int* cand_labels;
+    const int* cand_count;
+    int L, N, topk, Tmax, words;       // Tmax = roundup(L*topk, 64); words = Tmax/64
+    float nms_thresh, conf_thresh;
+    int max_keep;                      // detections_per_img
+    const float* ratios;               // [N][2] (ratio_h, ratio_w) = orig / resized
+    float* s_boxes; float* s_scores; int* s_labels; float* s_off; int* s_total;   // sorted scratch
+    unsigned long long* mask;          // [N][Tmax][words]
+    float* out_boxes; float* out_scores; long long* out_labels; int* out_count; int* out_conf_count;
+};
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // SORT_CAP entries (64 KiB)
+    __shared__ int offs[MAX_LEVELS + 1];
+    __shared__ float s_max[16];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int slot = a.L * a.topk;
+    if (tid == 0) {
+        int t = 0;
+        for (int l = 0; l < a.L; ++l) { offs[l] = t; t += a.cand_count[img * a.L + l]; }
+        offs[a.L] = t;
+    }
+    __syncthreads();
+    const int T = offs[a.L];
+    int npow = 1;
+    while (npow < T) npow <<= 1;
+    if (npow < 2) npow = 2;
+    float mx = -INFINITY;
+    for (int i = tid; i < npow; i += 1024) {
+        unsigned long long kv = 0ull;
+        if (i < T) {
+            int l = 0;
+            while (l + 1 < a.L && i >= offs[l + 1]) ++l;
+            const int src = l * a.topk + (i - offs[l]);
+            kv = ((unsigned long long)ordered_key(a.cand_logits[(size_t)img * slot + src]) << 32) |
+                 (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            const float4 b = *reinterpret_cast<const float4*>(a.cand_boxes + ((size_t)img * slot + src) * 4);
+            mx = fmaxf(mx, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+        }
+        keys[i] = kv;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+    __syncthreads();
+    mx = s_max[0];
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_max[w]);
+    bitonic_sort_desc(keys, npow, tid, 1024);
+    if (tid == 0) a.s_total[img] = T;
+    for (int r = tid; r < T; r += 1024) {
+        const int i = (int)(0xFFFFFFFFu - (unsigned)(keys[r] & 0xFFFFFFFFull));
+        int l = 0;
+        while (l + 1 < a.L && i >= offs[l + 1]) ++l;
+        const size_t src = (size_t)img * slot + l * a.topk + (i - offs[l]);
+        const size_t dst = (size_t)img * a.Tmax + r;
+        *reinterpret_cast<float4*>(a.s_boxes + dst * 4) = *reinterpret_cast<const float4*>(a.cand_boxes + src * 4);
+        a.s_scores[dst] = a.cand_scores[src];
+        const int lab = a.cand_labels[src];
+        a.s_labels[dst] = lab;
+        a.s_off[dst] = (float)lab * (mx + 1.f);   // batched_nms class offset (0 for num_classes == 1)
+    }
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
+    const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
+    const int T = a.s_total[img];
+    if (cb < rb || rb * 64 >= T || cb * 64 >= T) return;
+    __shared__ float4 cbox[64];
+    const int t = threadIdx.x;
+    {
+        const int j = cb * 64 + t;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < T) {
+            b = *reinterpret_cast<const float4*>(a.s_boxes + ((size_t)img * a.Tmax + j) * 4);
+            const float o = a.s_off[(size_t)img * a.Tmax + j];
+            b.x += o; b.y += o; b.z += o; b.w += o;
+        }
+        cbox[t] = b;
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= T) return;
+    float4 bi = *reinterpret_cast<const float4*>(a.s_boxes + ((size_t)img * a.Tmax + i) * 4);
+    {
+        const float o = a.s_off[(size_t)img * a.Tmax + i];
+        bi.x += o; bi.y += o; bi.z += o; bi.w += o;
+    }
+    const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+    unsigned long long bits = 0ull;
+    for (int jj = 0; jj < 64; ++jj) {
+        const int j = cb * 64 + jj;
+        if (j <= i || j >= T) continue;
+        const float4 bj = cbox[jj];
+        const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
+        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        const float iw = fmaxf(xx2 - xx1, 0.f), ih = fmaxf(yy2 - yy1, 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / (area_i + area_j - inter);
+        if (iou > a.nms_thresh) bits |= (1ull << jj);
+    }
+    a.mask[((size_t)img * a.Tmax + i) * a.words + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(NmsArgs a) {
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int T = a.s_total[img];
+    const int nw = (T + 63) / 64;
+    __shared__ int keep[SORT_CAP];
+    unsigned long long rem0 = 0ull, rem1 = 0ull;   // removed words `lane` and `lane + 64`
+    int nkept = 0;
+    const unsigned long long* M = a.mask + (size_t)img * a.Tmax * a.words;
+    for (int b = 0; b < nw && nkept < a.max_keep; ++b) {
+        unsigned long long src = (b < 64) ? rem0 : rem1;
+        unsigned long long cur = __shfl(src, b & 63);
+        const int row = b * 64 + lane;
+        unsigned long long diag = (row < T) ? M[(size_t)row * a.words + b] : 0ull;
+        const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
+        const int rows_here = (T - b * 64) < 64 ? (T - b * 64) : 64;
+        unsigned long long kept = 0ull;
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) {
+            const unsigned lo = __builtin_amdgcn_readlane(dlo, kk), hi = __builtin_amdgcn_readlane(dhi, kk);
+            if (kk < rows_here && !((cur >> kk) & 1ull)) {
+                kept |= (1ull << kk);
+                cur |= ((unsigned long long)hi << 32) | lo;
+            }
+        }
+        // record kept indices in order
+        if ((kept >> lane) & 1ull) {
+            int pos = nkept + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < SORT_CAP) keep[pos] = row;
+        }
+        nkept += __popcll(kept);
+        if (nkept >= a.max_keep) break;
+        // propagate the kept rows to the later words
+        const int w0 = lane, w1 = lane + 64;
+        const bool use0 = (w0 > b) && (w0 < nw), use1 = (w1 > b) && (w1 < nw);
+        unsigned long long kb = kept;
+        while (kb) {
+            const int k0 = __ffsll((long long)kb) - 1;
+            kb &= kb - 1ull;
+            const unsigned long long* r = M + (size_t)(b * 64 + k0) * a.words;
+            if (use0) rem0 |= r[w0];
+            if (use1) rem1 |= r[w1];
+        }
+    }
+    __syncthreads();
+    const int nout = nkept < a.max_keep ? nkept : a.max_keep;
+    const float rh = a.ratios[img * 2 + 0], rw = a.ratios[img * 2 + 1];
+    int nconf = 0;
+    for (int r = lane; r < nout; r += 64) {
+        const size_t src = (size_t)img * a.Tmax + keep[r];
+        const float4 bx = *reinterpret_cast<const float4*>(a.s_boxes + src * 4);
+        const size_t dst = (size_t)img * a.max_keep + r;
+        *reinterpret_cast<float4*>(a.out_boxes + dst * 4) = make_float4(bx.x * rw, bx.y * rh, bx.z * rw, bx.w * rh);
+        const float sc = a.s_scores[src];
+        a.out_scores[dst] = sc;
+        a.out_labels[dst] = (long long)a.s_labels[src];
+        nconf += (sc > a.conf_thresh) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nconf += __shfl_xor(nconf, off);
+    if (lane == 0) { a.out_count[img] = nout; a.out_conf_count[img] = nconf; }
+}
+
+extern "C" size_t cvpce_detect_workspace_bytes(int N, int L, int topk) {
+    const size_t slot = (size_t)L * topk;
+    const size_t Tmax = (slot + 63) / 64 * 64, words = Tmax / 64;
+    size_t b = 0;
+    b += (size_t)N * slot * (4 + 1 + 1 + 1) * 4;      // cand boxes/scores/logits/labels
+    b += (size_t)N * L * 4;                            // cand_count
+    b += (size_t)N * Tmax * (4 + 1 + 1 + 1) * 4;       // sorted boxes/scores/labels/off
+    b += (size_t)N * 4;                                // s_total
+    b += (size_t)N * Tmax * words * 8;                 // mask
+    return b + 1024;
+}
+
+extern "C" int cvpce_detect_postprocess(const float* const* logits, const float* const* regs, const int* gh,
+                                        const int* gw, const int* stride_h, const int* stride_w,
+                                        const float* base_anchors, const int* image_hw, const float* ratios, int L,
+                                        int N, int A, int K, int topk, float score_thresh, float nms_thresh,
+                                        float xform_clip, int detections_per_img, float conf_thresh, void* workspace,
+                                        size_t workspace_bytes, float* out_boxes, float* out_scores,
+                                        long long* out_labels, int* out_count, int* out_conf_count, void* stream) {
+    if (!logits || !regs || !gh || !gw || !stride_h || !stride_w || !base_anchors || !image_hw || !ratios ||
+        !workspace || !out_boxes || !out_scores || !out_labels || !out_count || !out_conf_count)
+        return CVPCE_ERR_ARG;
+    if (L < 1 || L > MAX_LEVELS || A < 1 || K < 1 || topk < 1 || topk > 1024 || detections_per_img < 1)
+        return CVPCE_ERR_ARG;
+    if ((size_t)L * topk > SORT_CAP || detections_per_img > SORT_CAP) return CVPCE_ERR_ARG;
+    if (N <= 0) return CVPCE_OK;
+    if (workspace_bytes < cvpce_detect_workspace_bytes(N, L, topk)) return CVPCE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t slot = (size_t)L * topk;
+    const size_t Tmax = (slot + 63) / 64 * 64, words = Tmax / 64;
+    char* p = (char*)workspace;
+    auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) / 256 * 256; return (void*)q; };
+    // mask first: keeps 8-byte alignment trivially
+    unsigned long long* mask = (unsigned long long*)take((size_t)N * Tmax * words * 8);
+    float* cand_boxes = (float*)take((size_t)N * slot * 16);
+    float* cand_scores = (float*)take((size_t)N * slot * 4);
+    float* cand_logits = (float*)take((size_t)N * slot * 4);
+    int* cand_labels = (int*)take((size_t)N * slot * 4);
+    int* cand_count = (int*)take((size_t)N * L * 4);
+    float* s_boxes = (float*)take((size_t)N * Tmax * 16);
+    float* s_scores = (float*)take((size_t)N * Tmax * 4);
+    int* s_labels = (int*)take((size_t)N * Tmax * 4);
+    float* s_off = (float*)take((size_t)N * Tmax * 4);
+    int* s_total = (int*)take((size_t)N * 4);
+    if ((size_t)(p - (char*)workspace) > workspace_bytes) return CVPCE_ERR_ARG;
+
+    DecodeArgs d;
+    for (int l = 0; l < L; ++l) {
+        if (!logits[l] || !regs[l] || gh[l] < 1 || gw[l] < 1) return CVPCE_ERR_ARG;
+        d.logits[l] = logits[l]; d.regs[l] = regs[l];
+        d.gh[l] = gh[l]; d.gw[l] = gw[l]; d.sh[l] = stride_h[l]; d.sw[l] = stride_w[l];
+    }
+    d.base_anchors = base_anchors; d.image_hw = image_hw; d.L = L; d.N = N; d.A = A; d.K = K; d.topk = topk;
+    d.score_thresh = score_thresh; d.xform_clip = xform_clip;
+    d.cand_boxes = cand_boxes; d.cand_scores = cand_scores; d.cand_logits = cand_logits; d.cand_labels = cand_labels;
+    d.cand_count = cand_count;
+    hipLaunchKernelGGL(decode_topk_kernel, dim3(L, N), dim3(1024), 0, s, d);
+
+    NmsArgs n;
+    n.cand_boxes = cand_boxes; n.cand_scores = cand_scores; n.cand_logits = cand_logits; n.cand_labels = cand_labels;
+    n.cand_count = cand_count; n.L = L; n.N = N; n.topk = topk; n.Tmax = (int)Tmax; n.words = (int)words;
+    n.nms_thresh = nms_thresh; n.conf_thresh = conf_thresh; n.max_keep = detections_per_img; n.ratios = ratios;
+    n.s_boxes = s_boxes; n.s_scores = s_scores; n.s_labels = s_labels; n.s_off = s_off; n.s_total = s_total;
+    n.mask = mask; n.out_boxes = out_boxes; n.out_scores = out_scores; n.out_labels = out_labels;
+    n.out_count = out_count; n.out_conf_count = out_conf_count;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SORT_CAP * 8) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(1024), SORT_CAP * 8, s, n);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, N), dim3(64), 0, s, n);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(64), 0, s, n);
+    return cvpce_check_launch();
+}

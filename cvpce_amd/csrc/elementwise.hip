@@ -1,0 +1,140 @@
+// HBM-bound helper kernels of the hot path (NHWC bf16, 16 B per lane):
+//   max-pool (VGG 2x2 s2, ResNet stem 3x3 s2 p1), ReLU, MAC global max over
+//   H,W (classification.py:46-49 `amax`), L2 normalisation with clamp
+//   (classification.py:51).
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+#include <math.h>
+
+__device__ __forceinline__ uint4 max_bf16x8(uint4 a, uint4 b) {
+    bf16x8 x = *reinterpret_cast<bf16x8*>(&a), y = *reinterpret_cast<bf16x8*>(&b), r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = ((float)x[i] > (float)y[i]) ? x[i] : y[i];
+    return *reinterpret_cast<uint4*>(&r);
+}
+
+__global__ void maxpool_nhwc_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int N, int H, int W,
+                                    int C, int k, int stride, int pad, int Ho, int Wo) {
+    const int C8 = C / 8;
+    const long long total = (long long)N * Ho * Wo * C8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % C8);
+        long long p = i / C8;
+        int ox = (int)(p % Wo);
+        p /= Wo;
+        int oy = (int)(p % Ho);
+        int n = (int)(p / Ho);
+        bf16x8 neg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) neg[j] = (bf16_t)(-INFINITY);
+        uint4 acc = *reinterpret_cast<uint4*>(&neg);
+        for (int dy = 0; dy < k; ++dy) {
+            int iy = oy * stride - pad + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                int ix = ox * stride - pad + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                uint4 v = *reinterpret_cast<const uint4*>(in + ((size_t)(n * H + iy) * W + ix) * C + c8 * 8);
+                acc = max_bf16x8(acc, v);
+            }
+        }
+        *reinterpret_cast<uint4*>(out + ((size_t)(n * Ho + oy) * Wo + ox) * C + c8 * 8) = acc;
+    }
+}
+
+extern "C" int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride,
+                                         int pad, int Ho, int Wo, void* stream) {
+    if (!in || !out || C % 8 != 0 || k < 1 || stride < 1) return CVPCE_ERR_ARG;
+    if (Ho != (H + 2 * pad - k) / stride + 1 || Wo != (W + 2 * pad - k) / stride + 1) return CVPCE_ERR_ARG;
+    long long total = (long long)N * Ho * Wo * (C / 8);
+    if (total <= 0) return CVPCE_OK;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+                       (bf16_t*)out, N, H, W, C, k, stride, pad, Ho, Wo);
+    return cvpce_check_launch();
+}
+
+__global__ void relu_bf16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long n8) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        uint4 v = in[i];
+        bf16x8 x = *reinterpret_cast<bf16x8*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = ((float)x[j] > 0.f) ? x[j] : (bf16_t)0.f;
+        out[i] = *reinterpret_cast<uint4*>(&x);
+    }
+}
+
+extern "C" int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream) {
+    if (!in || !out || n % 8 != 0) return CVPCE_ERR_ARG;
+    long long n8 = n / 8;
+    if (n8 == 0) return CVPCE_OK;
+    int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(relu_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n8);
+    return cvpce_check_launch();
+}
+
+// Global max over H*W for each (image, channel): block = (64-channel slab, image);
+// 256 threads = 8 channel-octets x 32 pixel lanes, 16 B loads, LDS tree over the pixel lanes.
+__global__ void global_max_nhwc_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int HW, int C,
+                                       int out_stride, int out_off) {
+    __shared__ float red[32][65];
+    const int n = blockIdx.y, cs = blockIdx.x * 64;
+    const int o = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    const bf16_t* base = in + (size_t)n * HW * C + cs + o * 8;
+    if (cs + o * 8 < C) {
+        for (int p = pl; p < HW; p += 32) {
+            uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)p * C);
+            bf16x8 x = *reinterpret_cast<bf16x8*>(&v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)x[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[pl][o * 8 + j] = m[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = -INFINITY;
+        for (int p = 0; p < 32; ++p) v = fmaxf(v, red[p][threadIdx.x]);
+        if (cs + threadIdx.x < C) out[(size_t)n * out_stride + out_off + cs + threadIdx.x] = v;
+    }
+}
+
+extern "C" int cvpce_global_max_nhwc_bf16(const void* in, float* out, int N, int HW, int C, int out_stride,
+                                          int out_off, void* stream) {
+    if (!in || !out || C % 8 != 0 || HW <= 0) return CVPCE_ERR_ARG;
+    if (N <= 0) return CVPCE_OK;
+    hipLaunchKernelGGL(global_max_nhwc_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, out, HW, C, out_stride, out_off);
+    return cvpce_check_launch();
+}
+
+// desc / ||desc||_2.clamp(min=eps); one wave per row.
+__global__ void l2_normalize_kernel(const float* __restrict__ in, float* __restrict__ out, bf16_t* __restrict__ out_bf16,
+                                    int B, int D, float eps) {
+    const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* x = in + (size_t)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += x[i] * x[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    float nrm = fmaxf(sqrtf(s), eps);
+    for (int i = lane; i < D; i += 64) {
+        float v = x[i] / nrm;
+        out[(size_t)row * D + i] = v;
+        if (out_bf16) out_bf16[(size_t)row * D + i] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int cvpce_l2_normalize_f32(const float* in, float* out, void* out_bf16, int B, int D, float eps, void* stream) {
+    if (!in || !out || D <= 0) return CVPCE_ERR_ARG;
+    if (B <= 0) return CVPCE_OK;
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (bf16_t*)out_bf16, B, D, eps);
+    return cvpce_check_launch();
+}

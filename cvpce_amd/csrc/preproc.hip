@@ -1,0 +1,162 @@
+// Input-side gather kernels (HBM-bound):
+//   K0  GeneralizedRCNNTransform (torchvision 0.9):
+//       per-channel normalise, bilinear resize (align_corners=False, scale =
+//       in/out), zero pad to the batch shape -> NHWC8 bf16 (3 real channels +
+//       5 zero channels so the stem conv can gather 16-byte K-chunks).
+//   K9  RoI crop (production.py:20: boxes.to(long) truncation, crop from the
+//       ORIGINAL image) + pad to square with 0.5, top-left anchored
+//       (datautils.py:234-238) + bilinear resize to 256x256 (ttf.resize on a
+//       tensor in torchvision 0.9 = F.interpolate bilinear, no antialias),
+//       optionally fused with scale_to_tanh (utils.py:280-281) and the MACVGG
+//       input normalisation (classification.py:41-44) writing NHWC8 bf16.
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+#pragma clang fp contract(off)
+
+// PyTorch area_pixel_compute_source_index (align_corners=False, non-cubic)
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ void gln_transform_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int H0, int W0, int h,
+                                     int w, int Hp, int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wp) return;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+    if (y < h && x < w) {
+        const float sy = (float)H0 / (float)h, sx = (float)W0 / (float)w;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(sy, y, H0, y0, y1, ly0, ly1);
+        src_index(sx, x, W0, x0, x1, lx0, lx1);
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* p = img + (size_t)c * H0 * W0;
+            float v00 = (p[(size_t)y0 * W0 + x0] - mean[c]) / stdv[c];
+            float v01 = (p[(size_t)y0 * W0 + x1] - mean[c]) / stdv[c];
+            float v10 = (p[(size_t)y1 * W0 + x0] - mean[c]) / stdv[c];
+            float v11 = (p[(size_t)y1 * W0 + x1] - mean[c]) / stdv[c];
+            float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            o[c] = f32_to_bf16(v);
+        }
+    }
+    *reinterpret_cast<bf16x8*>(out + ((size_t)y * Wp + x) * 8) = o;
+}
+
+extern "C" int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
+                                   const float* mean3, const float* std3, void* stream) {
+    if (!img || !out_nhwc8 || !mean3 || !std3) return CVPCE_ERR_ARG;
+    if (h > Hp || w > Wp || h <= 0 || w <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
+    dim3 grid((Wp + 127) / 128, Hp);
+    hipLaunchKernelGGL(gln_transform_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, (bf16_t*)out_nhwc8, H0, W0,
+                       h, w, Hp, Wp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    return cvpce_check_launch();
+}
+
+// One block row per (crop, output row); boxes are read on the device (no host sync).
+// mode 0: f32 NCHW in [0,1] (the reference's `resize_for_classification` output)
+// mode 1: bf16 NHWC8, scale_to_tanh + MACVGG normalisation fused
+__global__ void crop_resize_kernel(const float* __restrict__ img, const float* __restrict__ boxes,
+                                   const int* __restrict__ count, void* __restrict__ out, int H0, int W0, int S,
+                                   int mode, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int p = blockIdx.z;
+    if (count && p >= *count) return;
+    const int oy = blockIdx.y;
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= S) return;
+    const float* b = boxes + (size_t)p * 4;
+    // .to(torch.long): truncation toward zero; Python slice clamping to the image
+    long long x1 = (long long)b[0], y1 = (long long)b[1], x2 = (long long)b[2], y2 = (long long)b[3];
+    x1 = x1 < 0 ? 0 : (x1 > W0 ? W0 : x1);
+    x2 = x2 < 0 ? 0 : (x2 > W0 ? W0 : x2);
+    y1 = y1 < 0 ? 0 : (y1 > H0 ? H0 : y1);
+    y2 = y2 < 0 ? 0 : (y2 > H0 ? H0 : y2);
+    int cw = (int)(x2 - x1), ch = (int)(y2 - y1);
+    if (cw < 0) cw = 0;
+    if (ch < 0) ch = 0;
+    const int larger = cw > ch ? cw : ch;
+    float v[3] = {0.5f, 0.5f, 0.5f};
+    if (larger > 0) {
+        const float sc = (float)larger / (float)S;
+        int yy0, yy1, xx0, xx1;
+        float ly0, ly1, lx0, lx1;
+        src_index(sc, oy, larger, yy0, yy1, ly0, ly1);
+        src_index(sc, ox, larger, xx0, xx1, lx0, lx1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* pl = img + (size_t)c * H0 * W0;
+            auto at = [&](int yy, int xx) -> float {
+                return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
+            };
+            v[c] = ly0 * (lx0 * at(yy0, xx0) + lx1 * at(yy0, xx1)) + ly1 * (lx0 * at(yy1, xx0) + lx1 * at(yy1, xx1));
+        }
+    }
+    if (mode == 0) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)p * 3 * S * S;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[(size_t)c * S * S + (size_t)oy * S + ox] = v[c];
+    } else {
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = f32_to_bf16((v[c] * 2.f - 1.f - mean[c]) / stdv[c]);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (((size_t)p * S + oy) * S + ox) * 8) = o;
+    }
+}
+
+extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
+                                 int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream) {
+    if (!img || !boxes || !out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
+    if (mode == 1 && (!mean3 || !std3)) return CVPCE_ERR_ARG;
+    if (max_boxes <= 0) return CVPCE_OK;
+    if (max_boxes > 65535) return CVPCE_ERR_ARG;
+    dim3 grid((S + 127) / 128, S, max_boxes);
+    float m[3] = {0, 0, 0}, s[3] = {1, 1, 1};
+    if (mode == 1) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; s[i] = std3[i]; }
+    hipLaunchKernelGGL(crop_resize_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, out, H0, W0,
+                       S, mode, m[0], m[1], m[2], s[0], s[1], s[2]);
+    return cvpce_check_launch();
+}
+
+// (B,3,S,S) f32 NCHW -> NHWC8 bf16 with optional scale_to_tanh then (x - mean) / std.
+__global__ void pack_embed_input_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long npix, int SS,
+                                        int to_tanh, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        long long b = i / SS;
+        int p = (int)(i - b * SS);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = in[((size_t)b * 3 + c) * SS + p];
+            if (to_tanh) v = v * 2.f - 1.f;
+            o[c] = f32_to_bf16((v - mean[c]) / stdv[c]);
+        }
+        *reinterpret_cast<bf16x8*>(out + (size_t)i * 8) = o;
+    }
+}
+
+extern "C" int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int to_tanh, const float* mean3,
+                                      const float* std3, void* stream) {
+    if (!in || !out_nhwc8 || !mean3 || !std3 || S <= 0) return CVPCE_ERR_ARG;
+    long long npix = (long long)B * S * S;
+    if (npix <= 0) return CVPCE_OK;
+    int blocks = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_embed_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out_nhwc8,
+                       npix, S * S, to_tanh, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    return cvpce_check_launch();
+}

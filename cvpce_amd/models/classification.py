@@ -1,0 +1,169 @@
+"""MAC-VGG16 product embedder + cosine matcher on MI355X -- drop-in for
+/root/reference/cvpce/models/classification.py (`MACVGG`, `macvgg_embedder`,
+`distance`, `nearest_neighbors`; inference only -- the GAN wrappers and
+MACResNet are training / optional).
+
+nn.Modules hold parameters under the reference's state-dict keys
+(`block1.{0,2,5,...}`, `block2.{24,26,28}`: torchvision `features` indices
+survive the slicing at classification.py:36-37); the forward pass is a schedule
+of HIP kernels: 13 MFMA implicit-GEMM 3x3 convolutions with fused bias+ReLU,
+4 max-pools, two global-max (MAC) reductions and an L2 normalisation.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+
+VGG_CFGS = {'D': (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M')}
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+# classification.py:41-44: ImageNet statistics rescaled to the [-1, 1] input range
+TANH_MEAN = tuple(m * 2 - 1 for m in IMAGENET_MEAN)
+TANH_STD = tuple(s * 2 for s in IMAGENET_STD)
+INPUT_SIZE = 256
+MAX_EMBED_BATCH = 256  # crops per kernel schedule pass (keeps every NHWC tensor < 2^31 elements)
+
+
+def _vgg_features(cfg, batch_norm):
+    layers, cin = [], 3
+    for v in cfg:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            conv = nn.Conv2d(cin, v, kernel_size=3, padding=1)
+            nn.init.kaiming_normal_(conv.weight, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(conv.bias, 0)
+            layers += [conv, nn.BatchNorm2d(v), nn.ReLU(inplace=True)] if batch_norm else [conv, nn.ReLU(inplace=True)]
+            cin = v
+    return layers
+
+
+class MACVGGEngine:
+    def __init__(self, model, device):
+        self.plan = []
+        mods = list(model.block1) + ['desc1'] + list(model.block2)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, str):
+                self.plan.append(('desc', None))
+            elif isinstance(m, nn.MaxPool2d):
+                self.plan.append(('pool', None))
+            elif isinstance(m, nn.Conv2d):
+                scale = shift = None
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+                    bn = mods[i + 1]
+                    scale = bn.weight * (bn.running_var + bn.eps).rsqrt()
+                    shift = bn.bias - bn.running_mean * scale
+                self.plan.append(('conv', ops.PackedConv(m.weight, m.bias, 1, 1, scale=scale, shift=shift, device=device)))
+            i += 1
+        self.device = device
+        self.embedding_size = model.embedding_size
+
+    def embed_packed(self, x, eps=1e-8, want_bf16=False):
+        """x: (B,256,256,8) bf16, already normalised -> (B,1024) f32 unit-norm [, bf16 copy]."""
+        outs, outs_bf = [], []
+        for s in range(0, x.shape[0], MAX_EMBED_BATCH):
+            xb = x[s:s + MAX_EMBED_BATCH]
+            desc = torch.empty((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)
+            off = 0
+            for kind, pc in self.plan:
+                if kind == 'conv':
+                    xb = ops.conv2d(xb, pc, act=1)
+                elif kind == 'pool':
+                    xb = ops.maxpool2d(xb, 2, 2)
+                else:
+                    ops.global_max_into(xb, desc, off)
+                    off += xb.shape[3]
+            ops.global_max_into(xb, desc, off)
+            r = ops.l2_normalize(desc, eps, want_bf16)
+            if want_bf16:
+                outs.append(r[0]); outs_bf.append(r[1])
+            else:
+                outs.append(r)
+        if not outs:
+            e = torch.empty((0, self.embedding_size), dtype=torch.float32, device=x.device)
+            return (e, e.to(torch.bfloat16)) if want_bf16 else e
+        if want_bf16:
+            return torch.cat(outs), torch.cat(outs_bf)
+        return torch.cat(outs)
+
+
+class MACVGG(nn.Module):
+    """classification.py:20-51.  forward((B,3,256,256) in [-1,1]) -> (B,1024) unit-norm MAC descriptor."""
+
+    embedding_size = 512 * 2
+
+    def __init__(self, config='D', convs_per_block=[2, 2, 3, 3, 3], batch_norm=True, vgg_state_dict=None):
+        super().__init__()
+        feats = _vgg_features(VGG_CFGS[config], batch_norm)
+        if vgg_state_dict is not None:
+            holder = nn.Module()
+            holder.features = nn.Sequential(*feats)
+            holder.load_state_dict({k: v for k, v in vgg_state_dict.items() if k.startswith('features.')}, strict=True)
+        per_conv = 3 if batch_norm else 2
+        per_block = [c * per_conv + 1 for c in convs_per_block]
+        cut1, cut2 = sum(per_block[:-1]) - 1, sum(per_block) - 1
+        named = [(str(i), m) for i, m in enumerate(feats)]
+        self.block1 = nn.Sequential(OrderedDict(named[:cut1]))
+        self.block2 = nn.Sequential(OrderedDict(named[cut1:cut2]))
+        self._engine = None
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('MACVGG runs on an MI355X (HIP) device only: call .cuda() first (no CPU fallback).')
+        if self._engine is None:
+            self._engine = MACVGGEngine(self, dev)
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, x, eps=1e-8):
+        eng = self.engine()
+        x = x.to(device=eng.device, dtype=torch.float32)
+        packed = ops.pack_embed_input(x, False, TANH_MEAN, TANH_STD)
+        return eng.embed_packed(packed, eps)
+
+
+def distance(emb1, emb2, dim=1):
+    """classification.py:87-88 (elementwise form; plumbing-sized, plain torch on the caller's device)."""
+    return 1 - torch.nn.functional.cosine_similarity(emb1, emb2, dim=dim)
+
+
+@torch.no_grad()
+def nearest_neighbors(anchors, queries, k=1, dtype=torch.float32):
+    """classification.py:90-95 -> (Q,k) int64 indices into `anchors`, ascending cosine distance.
+
+    One MFMA GEMM with a fused top-k epilogue (csrc/match.hip).  dtype=float32 uses the exact-f32
+    matrix pipe (index-exact vs the fp32 oracle on tie-free data); bfloat16 is the fast path.
+    Ties resolve to the lower index (the reference's unstable argsort leaves them unspecified).
+    """
+    if not anchors.is_cuda or not queries.is_cuda:
+        raise RuntimeError('nearest_neighbors runs on an MI355X (HIP) device only (no CPU fallback)')
+    if len(queries) == 0:
+        return torch.empty((0, k), dtype=torch.int64, device=queries.device)
+    a = ops.pad_features(anchors.to(dtype))
+    q = ops.pad_features(queries.to(dtype))
+    return ops.match_topk(q, a, k)
+
+
+def macvgg_embedder(model='vgg16_bn', pretrained=True, progress=True):
+    """classification.py:97-109.  No network here: `pretrained=True` is rejected."""
+    model_to_config = {'vgg16': ('D', False), 'vgg16_bn': ('D', True)}
+    if model not in model_to_config:
+        raise NotImplementedError(f'MACVGG not implemented for {model}')
+    if pretrained:
+        raise RuntimeError('pretrained VGG weights cannot be downloaded here; use pretrained=False and load_state_dict')
+    config, batchnorm = model_to_config[model]
+    return MACVGG(config, batch_norm=batchnorm)

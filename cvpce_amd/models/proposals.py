@@ -1,0 +1,427 @@
+"""GLN dense-product detector on MI355X -- drop-in for
+/root/reference/cvpce/models/proposals.py (`gln`, `gln_backbone`,
+`GaussianLayerNetwork`; inference only).
+
+The reference builds the detector by subclassing torchvision 0.9's RetinaNet
+(proposals.py:162-168) over ResNet-50(FrozenBN)+FPN(+P6,P7) and adds a Gaussian
+branch fed by C2 and P3 (proposals.py:109-139).  Here the nn.Modules are only
+*parameter containers* that reproduce the reference's state-dict key names
+ so released checkpoints load unchanged; the forward pass is a
+fixed schedule of hand-written HIP kernels (cvpce_amd/csrc) over NHWC bf16
+activations -- transform gather, MFMA implicit-GEMM convolutions with folded
+FrozenBN/BN and fused residual / upsample-add / ReLU epilogues, LDS radix-select
+top-k, bitmask NMS.  There is no CPU path: tensors must live on a HIP device.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+
+# ---- torchvision 0.9 RetinaNet / transform constants ----
+MIN_SIZE, MAX_SIZE, SIZE_DIVISIBLE = 800, 1333, 32
+IMAGE_MEAN = (0.485, 0.456, 0.406)
+IMAGE_STD = (0.229, 0.224, 0.225)
+SCORE_THRESH, NMS_THRESH, TOPK_CANDIDATES = 0.05, 0.5, 1000
+BBOX_XFORM_CLIP = math.log(1000.0 / 16)
+ANCHOR_SIZES = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in (32, 64, 128, 256, 512))
+ASPECT_RATIOS = (0.5, 1.0, 2.0)
+FPN_CHANNELS = 256
+
+
+# ---------------------------------------------------------------------------
+# parameter containers (state-dict compatible with the reference checkpoints)
+# ---------------------------------------------------------------------------
+class FrozenBatchNorm2d(nn.Module):
+    """Buffers only, like torchvision.ops.misc.FrozenBatchNorm2d (eps 1e-5)."""
+    eps = 1e-5
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer('weight', torch.ones(n))
+        self.register_buffer('bias', torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        state_dict.pop(prefix + 'num_batches_tracked', None)
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def affine(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+
+def _conv(cin, cout, k, stride=1, pad=0, bias=True):
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=bias)
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(inplanes, planes, 1, bias=False), FrozenBatchNorm2d(planes)
+        self.conv2, self.bn2 = _conv(planes, planes, 3, stride, 1, bias=False), FrozenBatchNorm2d(planes)
+        self.conv3, self.bn3 = _conv(planes, planes * 4, 1, bias=False), FrozenBatchNorm2d(planes * 4)
+        if downsample:
+            self.downsample = nn.Sequential(_conv(inplanes, planes * 4, 1, stride, bias=False),
+                                            FrozenBatchNorm2d(planes * 4))
+        else:
+            self.downsample = None
+        self.stride = stride
+
+
+class _ResNet50(nn.Module):
+    """torchvision resnet50(norm_layer=FrozenBatchNorm2d) without avgpool/fc forward use."""
+    inplanes = 2048
+
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(3, 64, 7, 2, 3, bias=False), FrozenBatchNorm2d(64)
+        inpl = 64
+        for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3))):
+            layer = []
+            for bi in range(blocks):
+                stride = 2 if (bi == 0 and li > 0) else 1
+                layer.append(_Bottleneck(inpl, planes, stride, downsample=(bi == 0)))
+                inpl = planes * 4
+            setattr(self, f'layer{li + 1}', nn.Sequential(*layer))
+        self.fc = nn.Linear(2048, 1000)  # present in torchvision's resnet50; dropped by IntermediateLayerGetter
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+
+class _P6P7(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.p6, self.p7 = _conv(cin, cout, 3, 2, 1), _conv(cout, cout, 3, 2, 1)
+        for m in (self.p6, self.p7):
+            nn.init.kaiming_uniform_(m.weight, a=1)
+            nn.init.constant_(m.bias, 0)
+        self.use_P5 = cin == cout
+
+
+class _FPN(nn.Module):
+    def __init__(self, in_channels_list, out_channels):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList(_conv(c, out_channels, 1) for c in in_channels_list)
+        self.layer_blocks = nn.ModuleList(_conv(out_channels, out_channels, 3, 1, 1) for _ in in_channels_list)
+        for m in list(self.inner_blocks) + list(self.layer_blocks):
+            nn.init.kaiming_uniform_(m.weight, a=1)
+            nn.init.constant_(m.bias, 0)
+        self.extra_blocks = _P6P7(out_channels, out_channels)
+
+
+class _ConvNorm(nn.Module):
+    """keys `.conv.*`, `.norm.*` (GaussianLayerBlock, proposals.py:51-63)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv, self.norm = _conv(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout)
+        nn.init.kaiming_normal_(self.conv.weight, nonlinearity='relu')
+        nn.init.constant_(self.conv.bias, 0)
+
+
+class GaussianLayer(nn.Module):
+    """Containers for proposals.py:65-79: lateral 1x1 on C2 + up2(P3), two conv+BN+ReLU blocks, up2."""
+
+    def __init__(self, c_channels, p_channels):
+        super().__init__()
+        self.lateral = _conv(c_channels, p_channels, 1)
+        self.block1 = _ConvNorm(p_channels, p_channels // 2)
+        self.block2 = _ConvNorm(p_channels // 2, p_channels // 4)
+        nn.init.xavier_normal_(self.lateral.weight)
+        nn.init.constant_(self.lateral.bias, 0)
+
+
+class _ConvAct(nn.Module):
+    def __init__(self, cin, cout, k, tanh=False):
+        super().__init__()
+        self.conv = _conv(cin, cout, k, 1, 1 if k > 1 else 0)
+        if tanh:
+            nn.init.xavier_normal_(self.conv.weight, gain=nn.init.calculate_gain('tanh'))
+        else:
+            nn.init.kaiming_normal_(self.conv.weight, nonlinearity='relu')
+        nn.init.constant_(self.conv.bias, 0)
+
+
+class GaussianSubnet(nn.Module):
+    """Containers for proposals.py:96-107: 3x3 c->c/2, 3x3, 3x3 ->c/4, 1x1, 1x1 ->1 (ReLU; last Tanh iff tanh)."""
+
+    def __init__(self, in_channels, tanh=False):
+        super().__init__()
+        c = in_channels
+        self.blocks = nn.Sequential(_ConvAct(c, c // 2, 3), _ConvAct(c // 2, c // 2, 3), _ConvAct(c // 2, c // 4, 3),
+                                    _ConvAct(c // 4, c // 4, 1), _ConvAct(c // 4, 1, 1, tanh))
+        self.tanh = tanh
+
+
+class BackboneWithFPNAndGaussians(nn.Module):
+    """proposals.py:109-139: body -> (C2 | C3..C5 -> FPN+P6,P7) + Gaussian branch on (C2, P3)."""
+
+    def __init__(self, backbone, tanh=False):
+        super().__init__()
+        self.body = backbone
+        if hasattr(self.body, 'fc'):
+            del self.body.fc  # IntermediateLayerGetter keeps modules up to layer4 only
+        in_channels_list = [(backbone.inplanes // 8) * 2 ** (i - 1) for i in (2, 3, 4)]
+        self.fpn = _FPN(in_channels_list, FPN_CHANNELS)
+        self.out_channels = FPN_CHANNELS
+        self.gaussian_layer = GaussianLayer(256, FPN_CHANNELS)
+        self.gaussian_subnet = GaussianSubnet(FPN_CHANNELS // 4, tanh)
+        self.gaussians = None
+
+    def get_gaussians(self):
+        g = self.gaussians
+        self.gaussians = None
+        return g
+
+
+class _HeadTower(nn.Module):
+    def __init__(self, channels, out_name, out_channels):
+        super().__init__()
+        layers = []
+        for _ in range(4):
+            layers += [_conv(channels, channels, 3, 1, 1), nn.ReLU()]
+        self.conv = nn.Sequential(*layers)  # conv keys 0,2,4,6
+        setattr(self, out_name, _conv(channels, out_channels, 3, 1, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.01)
+                nn.init.constant_(m.bias, 0)
+
+
+class _RetinaNetHead(nn.Module):
+    def __init__(self, channels, num_anchors, num_classes, prior_probability=0.01):
+        super().__init__()
+        self.classification_head = _HeadTower(channels, 'cls_logits', num_anchors * num_classes)
+        nn.init.constant_(self.classification_head.cls_logits.bias, -math.log((1 - prior_probability) / prior_probability))
+        self.regression_head = _HeadTower(channels, 'bbox_reg', num_anchors * 4)
+        nn.init.zeros_(self.regression_head.bbox_reg.bias)
+
+
+# ---------------------------------------------------------------------------
+# the HIP execution plan
+# ---------------------------------------------------------------------------
+def _base_anchors():
+    out = []
+    for sizes in ANCHOR_SIZES:
+        scales = torch.as_tensor(sizes, dtype=torch.float32)
+        ratios = torch.as_tensor(ASPECT_RATIOS, dtype=torch.float32)
+        h_r = torch.sqrt(ratios)
+        w_r = 1 / h_r
+        ws = (w_r[:, None] * scales[None, :]).view(-1)
+        hs = (h_r[:, None] * scales[None, :]).view(-1)
+        out.append((torch.stack([-ws, -hs, ws, hs], dim=1) / 2).round())
+    return torch.stack(out)  # (L, A, 4)
+
+
+def resized_hw(h, w):
+    scale = float(MIN_SIZE) / float(min(h, w))
+    if float(max(h, w)) * scale > MAX_SIZE:
+        scale = float(MAX_SIZE) / float(max(h, w))
+    return int(math.floor(float(h) * scale)), int(math.floor(float(w) * scale))
+
+
+class GLNEngine:
+    """Weights packed for the HIP kernels (bf16 [Cout][K], FrozenBN/BN folded) + the launch schedule."""
+
+    def __init__(self, model, device):
+        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, **kw)
+        body = model.backbone.body
+
+        def fold(conv, bn):
+            s, b = bn.affine()
+            return P(conv, scale=s, shift=b)
+
+        self.stem = fold(body.conv1, body.bn1)
+        self.layers = []
+        for li in range(4):
+            blocks = []
+            for blk in getattr(body, f'layer{li + 1}'):
+                blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), fold(blk.conv3, blk.bn3),
+                               fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+            self.layers.append(blocks)
+        fpn = model.backbone.fpn
+        self.inner = [P(m) for m in fpn.inner_blocks]
+        self.outer = [P(m) for m in fpn.layer_blocks]
+        self.p6, self.p7 = P(fpn.extra_blocks.p6), P(fpn.extra_blocks.p7)
+        gl = model.backbone.gaussian_layer
+
+        def fold_bn(blk):
+            bn = blk.norm
+            s = bn.weight * (bn.running_var + bn.eps).rsqrt()
+            return P(blk.conv, scale=s, shift=bn.bias - bn.running_mean * s)
+
+        self.g_lateral = P(gl.lateral)
+        self.g_block1, self.g_block2 = fold_bn(gl.block1), fold_bn(gl.block2)
+        self.g_subnet = [P(b.conv) for b in model.backbone.gaussian_subnet.blocks]
+        self.tanh = model.backbone.gaussian_subnet.tanh
+        ch, rh = model.head.classification_head, model.head.regression_head
+        self.cls_tower = [P(ch.conv[i]) for i in (0, 2, 4, 6)]
+        self.cls_out = P(ch.cls_logits)
+        self.reg_tower = [P(rh.conv[i]) for i in (0, 2, 4, 6)]
+        self.reg_out = P(rh.bbox_reg)
+        self.base_anchors = _base_anchors().to(device)
+        self.num_anchors = self.base_anchors.shape[1]
+        self.device = device
+
+    # -- stages ---------------------------------------------------------------
+    def transform(self, images):
+        sizes = [tuple(i.shape[-2:]) for i in images]
+        rs = [resized_hw(h, w) for h, w in sizes]
+        hp = int(math.ceil(max(r[0] for r in rs) / SIZE_DIVISIBLE) * SIZE_DIVISIBLE)
+        wp = int(math.ceil(max(r[1] for r in rs) / SIZE_DIVISIBLE) * SIZE_DIVISIBLE)
+        batch = torch.empty((len(images), hp, wp, 8), dtype=torch.bfloat16, device=self.device)
+        for i, (img, (h, w)) in enumerate(zip(images, rs)):
+            ops.gln_transform_into(img.contiguous(), batch, i, h, w, IMAGE_MEAN, IMAGE_STD)
+        return batch, sizes, rs
+
+    def body(self, x):
+        x = ops.conv2d(x, self.stem, act=1)
+        x = ops.maxpool2d(x, 3, 2, 1)
+        feats = []
+        for blocks in self.layers:
+            for c1, c2, c3, ds in blocks:
+                identity = ops.conv2d(x, ds) if ds is not None else x
+                y = ops.conv2d(x, c1, act=1)
+                y = ops.conv2d(y, c2, act=1)
+                x = ops.conv2d(y, c3, act=1, residual=identity)
+            feats.append(x)
+        return feats  # C2..C5
+
+    def fpn(self, c3, c4, c5):
+        i5 = ops.conv2d(c5, self.inner[2])
+        p5 = ops.conv2d(i5, self.outer[2])
+        i4 = ops.conv2d(c4, self.inner[1], residual=i5, res_mode=2)
+        p4 = ops.conv2d(i4, self.outer[1])
+        i3 = ops.conv2d(c3, self.inner[0], residual=i4, res_mode=2)
+        p3 = ops.conv2d(i3, self.outer[0])
+        p6 = ops.conv2d(p5, self.p6)
+        p7 = ops.conv2d(ops.relu(p6), self.p7)
+        return [p3, p4, p5, p6, p7]
+
+    def gaussian_branch(self, c2, p3):
+        x = ops.conv2d(c2, self.g_lateral, residual=p3, res_mode=2)       # lateral(C2) + up2(P3)
+        x = ops.conv2d(x, self.g_block1, act=1)
+        x = ops.conv2d(x, self.g_block2, act=1)
+        x = ops.conv2d(x, self.g_subnet[0], act=1, in_up_shift=1)         # conv over up2(x), never materialised
+        x = ops.conv2d(x, self.g_subnet[1], act=1)
+        x = ops.conv2d(x, self.g_subnet[2], act=1)
+        x = ops.conv2d(x, self.g_subnet[3], act=1)
+        return ops.conv2d(x, self.g_subnet[4], act=2 if self.tanh else 1, out_f32=True)  # (N,H/2,W/2,1) f32
+
+    def heads(self, feats):
+        cls, reg = [], []
+        for f in feats:
+            t = f
+            for pc in self.cls_tower:
+                t = ops.conv2d(t, pc, act=1)
+            cls.append(ops.conv2d(t, self.cls_out, out_f32=True))
+            t = f
+            for pc in self.reg_tower:
+                t = ops.conv2d(t, pc, act=1)
+            reg.append(ops.conv2d(t, self.reg_out, out_f32=True))
+        return cls, reg
+
+    def postprocess(self, cls, reg, padded_hw, resized, original, num_classes, detections_per_img, conf_thresh):
+        n = cls[0].shape[0]
+        grids = [(c.shape[1], c.shape[2]) for c in cls]
+        strides = [(padded_hw[0] // g[0], padded_hw[1] // g[1]) for g in grids]
+        logits = [c.view(n, -1) for c in cls]
+        regs = [r.view(n, -1, 4) for r in reg]
+        image_hw = torch.tensor(resized, dtype=torch.int32).to(self.device)
+        ratios = torch.stack([torch.tensor(o, dtype=torch.float32) / torch.tensor(r, dtype=torch.float32)
+                              for o, r in zip(original, resized)]).to(self.device)
+        return ops.detect_postprocess(logits, regs, grids, strides, self.base_anchors, image_hw, ratios,
+                                      self.num_anchors, num_classes, TOPK_CANDIDATES, SCORE_THRESH, NMS_THRESH,
+                                      BBOX_XFORM_CLIP, detections_per_img, conf_thresh)
+
+    def detect(self, images, num_classes, detections_per_img, conf_thresh=0.5, want_intermediates=False):
+        """-> (boxes (N,dpi,4), scores, labels, count, conf_count, gaussians (N,1,H/2,W/2)) all on device."""
+        batch, original, resized = self.transform(images)
+        c2, c3, c4, c5 = self.body(batch)
+        feats = self.fpn(c3, c4, c5)
+        gauss = self.gaussian_branch(c2, feats[0])
+        cls, reg = self.heads(feats)
+        out = self.postprocess(cls, reg, tuple(batch.shape[1:3]), resized, original, num_classes,
+                               detections_per_img, conf_thresh)
+        gauss = gauss.permute(0, 3, 1, 2)  # (N,1,h,w) view of the NHWC buffer (C == 1)
+        if want_intermediates:
+            return out + (gauss,), {'batch': batch, 'c': (c2, c3, c4, c5), 'features': feats, 'cls': cls, 'reg': reg}
+        return out + (gauss,)
+
+
+# ---------------------------------------------------------------------------
+# public API
+# ---------------------------------------------------------------------------
+class GaussianLayerNetwork(nn.Module):
+    """Drop-in for proposals.py:162-181 (eval mode): `model(list[Tensor(3,H,W)])` ->
+    `list[dict(boxes, scores, labels, gaussians)]`, boxes in original pixels, scores descending."""
+
+    def __init__(self, resnet, num_classes, gaussian_loss_params={}, tanh=False, detections_per_img=1000, **kwargs):
+        super().__init__()
+        if kwargs:
+            raise TypeError(f'unsupported RetinaNet overrides on the HIP path: {sorted(kwargs)}')
+        self.backbone = BackboneWithFPNAndGaussians(resnet, tanh=tanh)
+        self.head = _RetinaNetHead(FPN_CHANNELS, len(ASPECT_RATIOS) * len(ANCHOR_SIZES[0]), num_classes)
+        self.num_classes = num_classes
+        self.detections_per_img = detections_per_img
+        self.gaussian_loss_params = gaussian_loss_params
+        self._engine = None
+        self.eval()
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('GaussianLayerNetwork runs on an MI355X (HIP) device only: call .cuda() first. '
+                               'No CPU fallback exists in cvpce_amd (the CPU restatement lives in oracle/ for tests).')
+        if self._engine is None:
+            self._engine = GLNEngine(self, dev)
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, images, targets=None):
+        if self.training:
+            raise NotImplementedError('training is out of scope of the MI355X inference path (SURVEY.md 2)')
+        if torch.is_tensor(images):
+            images = list(images)
+        eng = self.engine()
+        images = [i.to(device=eng.device, dtype=torch.float32) for i in images]
+        boxes, scores, labels, count, _, gauss = eng.detect(images, self.num_classes, self.detections_per_img)
+        self.backbone.gaussians = gauss
+        counts = count.tolist()
+        res = [{'boxes': boxes[i, :c], 'scores': scores[i, :c], 'labels': labels[i, :c]} for i, c in enumerate(counts)]
+        for r, g in zip(res, self.backbone.get_gaussians()):
+            r['gaussians'] = g
+        return res
+
+
+def gln_backbone(trainable_layers=5, pretrained=True):
+    """proposals.py:183-191.  No network here: `pretrained=True` cannot download and is rejected."""
+    if pretrained:
+        raise RuntimeError('pretrained ImageNet weights cannot be downloaded here; build with '
+                           'pretrained_backbone=False and load a checkpoint via load_state_dict')
+    backbone = _ResNet50()
+    layers_to_train = ['layer4', 'layer3', 'layer2', 'layer1', 'conv1'][:trainable_layers]
+    for name, parameter in backbone.named_parameters():
+        if all(not name.startswith(layer) for layer in layers_to_train):
+            parameter.requires_grad_(False)
+    return backbone
+
+
+def gln(num_classes=1, trainable_layers=4, pretrained_backbone=True, tanh=False, gaussian_loss_params={},
+        detections_per_img=1000):
+    """proposals.py:202-203"""
+    return GaussianLayerNetwork(gln_backbone(trainable_layers, pretrained_backbone), num_classes, tanh=tanh,
+                                gaussian_loss_params=gaussian_loss_params, detections_per_img=detections_per_img)

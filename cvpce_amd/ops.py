@@ -1,0 +1,249 @@
+"""Tensor-level wrappers over the C ABI (include/cvpce_amd.h).
+
+torch is plumbing here: device memory (tensors), the current HIP stream and
+nothing else.  Every op runs a hand-written HIP kernel from libcvpce_hip.so;
+CPU tensors are rejected loudly.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('cvpce_amd ops run on the GPU only (HIP kernels); got a CPU tensor. '
+                               'There is no CPU fallback in the product path.')
+
+
+# ---------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------
+class PackedConv:
+    """bf16 [Cout_pad][K_pad] weight + fp32 bias, K = (kh*KW + kw)*Cin_pad + ci."""
+
+    def __init__(self, weight, bias=None, stride=1, pad=0, scale=None, shift=None, device='cuda'):
+        """weight (Cout,Cin,KH,KW) f32; optional per-Cout affine folded in:
+        y = conv(x, w) * scale + shift (+ bias * scale)  -- FrozenBN / BN-eval folding."""
+        w = weight.detach().to(torch.float32).cpu()
+        cout, cin, kh, kw = w.shape
+        b = bias.detach().to(torch.float32).cpu() if bias is not None else None
+        if scale is not None:
+            scale = scale.detach().to(torch.float32).cpu()
+            w = w * scale[:, None, None, None]
+            b = b * scale if b is not None else None
+        if shift is not None:
+            shift = shift.detach().to(torch.float32).cpu()
+            b = shift if b is None else b + shift
+        self.cin = cin
+        self.cin_pad = (cin + 7) // 8 * 8
+        self.cout, self.kh, self.kw, self.stride, self.pad = cout, kh, kw, stride, pad
+        k = kh * kw * self.cin_pad
+        self.k_pad = (k + 63) // 64 * 64
+        self.cout_pad = (cout + 127) // 128 * 128
+        wp = torch.zeros(self.cout_pad, kh, kw, self.cin_pad, dtype=torch.float32)
+        wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+        packed = torch.zeros(self.cout_pad, self.k_pad, dtype=torch.float32)
+        packed[:, :k] = wp.reshape(self.cout_pad, k)
+        self.weight = packed.to(BF16).to(device)
+        self.bias = b.to(device) if b is not None else None
+
+    def out_hw(self, h, w, in_up_shift=0):
+        h, w = h << in_up_shift, w << in_up_shift
+        return ((h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1)
+
+
+def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0, out=None):
+    """x: NHWC bf16 (N,H,W,Cin_pad) -> NHWC (N,Ho,Wo,Cout) bf16 | f32."""
+    _need_cuda(x, residual)
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    n, h, w, cin = x.shape
+    assert cin == pc.cin_pad, (cin, pc.cin_pad)
+    ho, wo = pc.out_hw(h, w, in_up_shift)
+    if out is None:
+        out = torch.empty((n, ho, wo, pc.cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    hr = wr = 0
+    if residual is not None:
+        assert residual.dtype == BF16 and residual.is_contiguous() and residual.shape[0] == n and residual.shape[3] == pc.cout
+        hr, wr = residual.shape[1], residual.shape[2]
+        if res_mode == 0:
+            res_mode = 1 if (hr, wr) == (ho, wo) else 2
+    rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
+                                    pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),
+                                    int(out_f32), int(in_up_shift), int(res_mode if residual is not None else 0),
+                                    hr, wr, _stream())
+    check(rc, 'cvpce_conv2d_nhwc_bf16')
+    return out
+
+
+def maxpool2d(x, k, stride, pad=0):
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.empty((n, ho, wo, c), dtype=BF16, device=x.device)
+    check(lib.cvpce_maxpool2d_nhwc_bf16(_p(x), _p(out), n, h, w, c, k, stride, pad, ho, wo, _stream()), 'maxpool')
+    return out
+
+
+def relu(x):
+    _need_cuda(x)
+    out = torch.empty_like(x)
+    check(lib.cvpce_relu_bf16(_p(x), _p(out), x.numel(), _stream()), 'relu')
+    return out
+
+
+def global_max_into(x, out, out_off):
+    """x NHWC bf16 -> out[:, out_off:out_off+C] (f32) = amax over H,W."""
+    _need_cuda(x, out)
+    n, h, w, c = x.shape
+    check(lib.cvpce_global_max_nhwc_bf16(_p(x), _p(out), n, h * w, c, out.shape[1], out_off, _stream()), 'global_max')
+
+
+def l2_normalize(desc, eps=1e-8, want_bf16=False):
+    _need_cuda(desc)
+    out = torch.empty_like(desc)
+    out_bf = torch.empty(desc.shape, dtype=BF16, device=desc.device) if want_bf16 else None
+    check(lib.cvpce_l2_normalize_f32(_p(desc), _p(out), _p(out_bf), desc.shape[0], desc.shape[1], eps, _stream()), 'l2norm')
+    return (out, out_bf) if want_bf16 else out
+
+
+# ---------------------------------------------------------------------------
+# input side
+# ---------------------------------------------------------------------------
+def gln_transform_into(img, batch, index, h, w, mean, std):
+    """img (3,H0,W0) f32 cuda -> batch[index] (Hp,Wp,8) bf16."""
+    _need_cuda(img, batch)
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    _, hp, wp, c8 = batch.shape
+    assert c8 == 8
+    check(lib.cvpce_gln_transform(_p(img), ctypes.c_void_p(batch[index].data_ptr()), img.shape[1], img.shape[2], h, w,
+                                  hp, wp, _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform')
+
+
+MAX_CROPS_PER_LAUNCH = 65535
+
+
+def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, out=None):
+    """img (3,H0,W0) f32, boxes (P,4) f32 xyxy (device) -> (P,3,S,S) f32 [mode 0] | (P,S,S,8) bf16 [mode 1]."""
+    _need_cuda(img, boxes)
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    boxes = boxes.to(torch.float32).contiguous()
+    p = boxes.shape[0]
+    if out is None:
+        out = (torch.empty((p, 3, size, size), dtype=torch.float32, device=img.device) if mode == 0
+               else torch.empty((p, size, size, 8), dtype=BF16, device=img.device))
+    m = _lib.float3(mean) if mean is not None else None
+    s = _lib.float3(std) if std is not None else None
+    for start in range(0, p, MAX_CROPS_PER_LAUNCH):
+        nb = min(MAX_CROPS_PER_LAUNCH, p - start)
+        cnt = None
+        if count is not None:
+            assert start == 0 and p <= MAX_CROPS_PER_LAUNCH
+            cnt = count
+        check(lib.cvpce_crop_resize(_p(img), ctypes.c_void_p(boxes[start:].data_ptr()), _p(cnt), nb,
+                                    ctypes.c_void_p(out[start:].data_ptr()), img.shape[1], img.shape[2], size, mode,
+                                    m, s, _stream()), 'crop_resize')
+    return out
+
+
+def pack_embed_input(images, to_tanh, mean, std):
+    """(B,3,S,S) f32 -> (B,S,S,8) bf16 normalised."""
+    _need_cuda(images)
+    images = images.to(torch.float32).contiguous()
+    b, _, s, s2 = images.shape
+    assert s == s2
+    out = torch.empty((b, s, s, 8), dtype=BF16, device=images.device)
+    check(lib.cvpce_pack_embed_input(_p(images), _p(out), b, s, int(to_tanh), _lib.float3(mean), _lib.float3(std),
+                                     _stream()), 'pack_embed_input')
+    return out
+
+
+# ---------------------------------------------------------------------------
+# detector post-processing
+# ---------------------------------------------------------------------------
+def detect_postprocess(logits, regs, grids, strides, base_anchors, image_hw, ratios, num_anchors, num_classes,
+                       topk, score_thresh, nms_thresh, xform_clip, detections_per_img, conf_thresh):
+    """logits[l] (N, gh*gw*A*K) f32, regs[l] (N, gh*gw*A, 4) f32 (views of the NHWC conv outputs).
+
+    Returns boxes (N,dpi,4), scores (N,dpi), labels (N,dpi) i64, count (N,) i32, conf_count (N,) i32.
+    """
+    _need_cuda(*logits, *regs, base_anchors, image_hw, ratios)
+    L, n = len(logits), logits[0].shape[0]
+    dev = logits[0].device
+    ws_bytes = lib.cvpce_detect_workspace_bytes(n, L, topk)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    boxes = torch.zeros((n, detections_per_img, 4), dtype=torch.float32, device=dev)
+    scores = torch.zeros((n, detections_per_img), dtype=torch.float32, device=dev)
+    labels = torch.zeros((n, detections_per_img), dtype=torch.int64, device=dev)
+    count = torch.zeros((n,), dtype=torch.int32, device=dev)
+    conf = torch.zeros((n,), dtype=torch.int32, device=dev)
+    for t in list(logits) + list(regs):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    lp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in logits])
+    rp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in regs])
+    ci = lambda v: (ctypes.c_int * L)(*[int(x) for x in v])
+    rc = lib.cvpce_detect_postprocess(lp, rp, ci([g[0] for g in grids]), ci([g[1] for g in grids]),
+                                      ci([s[0] for s in strides]), ci([s[1] for s in strides]),
+                                      _p(base_anchors), _p(image_hw), _p(ratios), L, n, num_anchors, num_classes,
+                                      topk, score_thresh, nms_thresh, xform_clip, detections_per_img, conf_thresh,
+                                      _p(ws), ws_bytes, _p(boxes), _p(scores), _p(labels), _p(count), _p(conf),
+                                      _stream())
+    check(rc, 'cvpce_detect_postprocess')
+    return boxes, scores, labels, count, conf
+
+
+# ---------------------------------------------------------------------------
+# matcher
+# ---------------------------------------------------------------------------
+def row_norms(x, eps=1e-8):
+    _need_cuda(x)
+    assert x.is_contiguous() and x.dtype in (BF16, torch.float32)
+    out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    check(lib.cvpce_row_norms(_p(x), _p(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32), eps, _stream()),
+          'row_norms')
+    return out
+
+
+def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distance=False):
+    """(Q,D), (G,D) same dtype (bf16 | f32), D % 64 == 0 -> (Q,k) int64 [+ (Q,k) f32 distances]."""
+    _need_cuda(queries, gallery)
+    assert queries.dtype == gallery.dtype and queries.dtype in (BF16, torch.float32)
+    assert queries.is_contiguous() and gallery.is_contiguous() and queries.shape[1] == gallery.shape[1]
+    qn, d = queries.shape
+    gn = gallery.shape[0]
+    if q_norms is None:
+        q_norms = row_norms(queries)
+    if g_norms is None:
+        g_norms = row_norms(gallery)
+    ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
+    idx = torch.empty((qn, k), dtype=torch.int64, device=queries.device)
+    dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
+    rc = lib.cvpce_match_topk(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), qn, gn, d, k,
+                              int(queries.dtype == torch.float32), _p(ws), ws_bytes, _p(idx), _p(dist), _stream())
+    check(rc, 'cvpce_match_topk')
+    return (idx, dist) if return_distance else idx
+
+
+def pad_features(x, multiple=64):
+    d = x.shape[1]
+    dp = (d + multiple - 1) // multiple * multiple
+    if dp == d:
+        return x.contiguous()
+    out = torch.zeros((x.shape[0], dp), dtype=x.dtype, device=x.device)
+    out[:, :d] = x
+    return out

@@ -1,0 +1,187 @@
+"""Pipeline objects on MI355X -- drop-in for /root/reference/cvpce/production.py
+(`ProposalGenerator` :8-20, `Classifier` :22-74, `PlanogramEvaluator` :118-129).
+
+Differences from the reference, all on the device-boundary side:
+  * crops / embeddings stay on the GPU (the reference builds crops on the CPU in a Python loop);
+  * `BatchedPipeline` runs detect -> crop -> embed -> match for a whole batch of shelf images with a
+    single host synchronisation at the end (the reference: one image, one box at a time);
+  * degenerate (zero-area after `.to(long)`) boxes make the reference raise inside
+    `resize_for_classification`; here they are dropped (documented divergence).
+"""
+import torch
+
+from . import datautils, ops
+from .models.classification import TANH_MEAN, TANH_STD
+
+
+def _nondegenerate(boxes):
+    b = boxes.to(torch.long)
+    return ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+
+
+class ProposalGenerator:
+    def __init__(self, detector, device=torch.device('cuda'), confidence_threshold=0.5):
+        self.detector = detector
+        self.device = device
+        self.condfidence_threshold = confidence_threshold  # (sic) production.py:12
+
+    def generate_proposals(self, image):
+        res = self.detector(image[None].to(self.device))[0]
+        return res['boxes'][res['scores'] > self.condfidence_threshold]
+
+    def generate_proposals_and_images(self, image):
+        boxes = self.generate_proposals(image)
+        size = datautils.CLASSIFICATION_IMAGE_SIZE
+        if len(boxes):
+            boxes = boxes[_nondegenerate(boxes)]
+        if not len(boxes):
+            return boxes, torch.empty((0, 3, size, size), device=self.device)
+        img = image.to(device=self.device, dtype=torch.float32).contiguous()
+        return boxes, ops.crop_resize(img, boxes, size, mode=0)
+
+
+class Classifier:
+    def __init__(self, encoder, sample_set, device=torch.device('cuda'), emb_device=torch.device('cuda'),
+                 batch_size=32, num_workers=8, k=1, load=None, verbose=False, match_dtype=torch.bfloat16):
+        self.batch_size = batch_size
+        self.num_workers = num_workers  # kept for signature parity; gallery tensors are batched in-process
+        self.device = device
+        self.emb_device = emb_device
+        self.k = k
+        self.encoder = encoder
+        self.match_dtype = match_dtype
+        if load is None:
+            self.embedding, self.annotations = self.build_index(sample_set, verbose)
+        else:
+            self.embedding, self.annotations = self.load_index(load)
+        self._refresh_gallery()
+
+    def _refresh_gallery(self):
+        """Device-resident gallery operand of the distance GEMM (+ its row norms), built once."""
+        g = ops.pad_features(self.embedding.to(device=self.device, dtype=self.match_dtype))
+        self._gallery = g
+        self._gallery_norms = ops.row_norms(g)
+
+    def set_index(self, embedding, annotations):
+        self.embedding, self.annotations = embedding, annotations
+        self._refresh_gallery()
+
+    def build_index(self, sample_set, verbose=False):
+        """production.py:36-48.  Gallery images are already in [-1,1] (datautils.py:446): no scale_to_tanh."""
+        chunks, annotations, imgs = [], [], []
+
+        def flush():
+            if imgs:
+                batch = torch.stack(imgs).to(device=self.device)
+                chunks.append(self.encoder(batch).detach().to(device=self.emb_device))
+                imgs.clear()
+
+        for i in range(len(sample_set)):
+            item = sample_set[i]
+            imgs.append(item[0])
+            annotations.append(item[-1])
+            if len(imgs) == self.batch_size:
+                if verbose and (i // self.batch_size) % 100 == 0:
+                    print(i // self.batch_size)
+                flush()
+        flush()
+        if chunks:
+            embedding = torch.cat(chunks)
+        else:
+            embedding = torch.empty((0, self.encoder.embedding_size), dtype=torch.float, device=self.emb_device)
+        return embedding, annotations
+
+    def save_index(self, pth):
+        torch.save({'embedding': self.embedding, 'annotations': self.annotations}, pth)
+
+    def load_index(self, pth):
+        idx = torch.load(pth)
+        return idx['embedding'], idx['annotations']
+
+    def match(self, emb):
+        """(P,1024) f32 unit-norm on device -> (P,k) int64 gallery indices."""
+        q = ops.pad_features(emb.to(self.match_dtype))
+        return ops.match_topk(q, self._gallery, self.k, g_norms=self._gallery_norms)
+
+    def classify(self, images, return_embedding=False):
+        """production.py:57-74: images (P,3,256,256) in [0,1] -> list[list[str]] (P x k)."""
+        res, embs = [], []
+        eng = self.encoder.engine()
+        for i in range(0, len(images), self.batch_size):
+            batch = images[i:i + self.batch_size].to(device=self.device)
+            packed = ops.pack_embed_input(batch, True, TANH_MEAN, TANH_STD)  # scale_to_tanh + normalise fused
+            emb = eng.embed_packed(packed)
+            if return_embedding:
+                embs.append(emb.to(device=self.emb_device))
+            nearest = self.match(emb).tolist()
+            res += [[self.annotations[j] for j in n] for n in nearest]
+        if return_embedding:
+            if embs:
+                return res, torch.cat(embs)
+            return res, torch.empty((0, self.encoder.embedding_size), dtype=torch.float, device=self.emb_device)
+        return res
+
+
+class PlanogramEvaluator:
+    """production.py:118-129 glue; `planogram_comparator` is any object with `.compare(expected, actual, image, classifier)`."""
+
+    def __init__(self, proposal_generator, classifier, planogram_comparator):
+        self.proposal_generator = proposal_generator
+        self.classifier = classifier
+        self.planogram_comparator = planogram_comparator
+
+    def evaluate(self, image, planogram):
+        boxes, images = self.proposal_generator.generate_proposals_and_images(image)
+        classes = [ann[0] for ann in self.classifier.classify(images)]
+        return self.planogram_comparator.compare(planogram, {'boxes': boxes.detach().cpu(), 'labels': classes},
+                                                 image, self.classifier)
+
+
+class BatchedPipeline:
+    """detect -> RoI crop -> embed -> match for a batch of shelf images, device-resident end to end.
+
+    Same arithmetic as ProposalGenerator.generate_proposals_and_images + Classifier.classify per image
+    (production.py:13-20,57-74) but: one detector pass for the whole batch, the crop kernel reads the
+    kept boxes and the confidence-prefix count straight from device memory and writes normalised
+    NHWC bf16 embedder input (no f32 crop tensor, no host round trip), one distance GEMM per batch.
+    """
+
+    def __init__(self, detector, classifier, confidence_threshold=0.5):
+        self.detector = detector
+        self.classifier = classifier
+        self.confidence_threshold = confidence_threshold
+
+    @torch.no_grad()
+    def run(self, images):
+        """images: list of (3,H,W) f32 cuda tensors -> dict of device tensors:
+        boxes (N,dpi,4), scores (N,dpi), count (N,) = #scores > confidence, indices (N,dpi,k) (-1 beyond count)."""
+        det = self.detector
+        eng = det.engine()
+        emb_eng = self.classifier.encoder.engine()
+        dpi = det.detections_per_img
+        size = datautils.CLASSIFICATION_IMAGE_SIZE
+        boxes, scores, labels, count, conf_count, gauss = eng.detect(images, det.num_classes, dpi,
+                                                                     self.confidence_threshold)
+        n = len(images)
+        crops = torch.empty((n * dpi, size, size, 8), dtype=torch.bfloat16, device=eng.device)
+        for i, img in enumerate(images):
+            ops.crop_resize(img, boxes[i], size, mode=1, mean=TANH_MEAN, std=TANH_STD, count=conf_count[i:i + 1],
+                            out=crops[i * dpi:(i + 1) * dpi])
+        # One host sync: the embedder only runs over the valid crops (compaction = a gather of row indices)
+        counts = conf_count.tolist()
+        if sum(counts) == n * dpi:
+            valid = crops
+            sel = None
+        else:
+            sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
+            valid = crops.index_select(0, sel)
+        emb = emb_eng.embed_packed(valid)
+        idx = self.classifier.match(emb)
+        k = idx.shape[1] if idx.numel() else self.classifier.k
+        indices = torch.full((n * dpi, k), -1, dtype=torch.int64, device=eng.device)
+        if sel is None:
+            indices = idx
+        elif idx.numel():
+            indices.index_copy_(0, sel, idx)
+        return {'boxes': boxes, 'scores': scores, 'labels': labels, 'count': conf_count, 'det_count': count,
+                'indices': indices.view(n, dpi, k), 'gaussians': gauss, 'embeddings': emb, 'counts_host': counts}

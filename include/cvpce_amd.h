@@ -1,0 +1,95 @@
+/* cvpce_amd -- C ABI of the MI355X (gfx950) hot path of laitalaj/cvpce.
+ *
+ * The reference has no FFI of its own (it is pure Python over PyTorch /
+ * torchvision); the drop-in boundary is its Python API.  This
+ * header is the layer directly under that API: plain pointers + sizes, no
+ * torch types.  Every pointer is a DEVICE pointer unless marked [host]; every
+ * call is asynchronous on `stream` (a hipStream_t passed as void*), performs no
+ * allocation and no synchronisation, and returns CVPCE_OK (0) or an error code
+ * (1 = bad argument, 2 = launch failure).  Citations are to /root/reference.
+ *
+ * Tensor layouts
+ *   activations : NHWC bf16, C % 8 == 0 (3-channel images are carried as C = 8,
+ *                 channels 3..7 zero)
+ *   conv weights: bf16 [Cout_pad][K_pad], K index = (kh*KW + kw)*Cin + ci,
+ *                 Cout_pad % 128 == 0, K_pad % 64 == 0, zero padded
+ *                 (FrozenBN / BatchNorm-eval already folded in by the host)
+ */
+#ifndef CVPCE_AMD_H
+#define CVPCE_AMD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVPCE_ACT_NONE 0
+#define CVPCE_ACT_RELU 1
+#define CVPCE_ACT_TANH 2 /* fp32 outputs only (GaussianSubnet tanh head, proposals.py:85) */
+
+/* Implicit-GEMM convolution + fused epilogue  out = act(conv(in) + bias + residual).
+ * Replaces every nn.Conv2d on the path: torchvision ResNet-50/FPN/RetinaNetHead/VGG16
+ *  and cvpce/models/proposals.py:54,68,84 (Gaussian branch).
+ *   in_up_shift 1 : the logical input is the nearest-2x upsample of `in`
+ *                   (GaussianLayer.forward `self.up(x)`, proposals.py:79) -- not materialised
+ *   res_mode 0/1/2: none / same-size residual (Bottleneck add) / nearest-resampled
+ *                   residual [N][Hr][Wr][Cout] (FPN top-down add; proposals.py:76)
+ *   out_f32       : NHWC fp32 output (head logits / box regressions / gaussians) */
+int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res, void* out,
+                           int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                           int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
+                           int res_mode, int Hr, int Wr, void* stream);
+
+/* nn.MaxPool2d (VGG 2x2 s2; ResNet stem 3x3 s2 p1), NHWC bf16 */
+int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
+                              int Ho, int Wo, void* stream);
+/* F.relu on a bf16 buffer (LastLevelP6P7: p7(F.relu(p6))) */
+int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream);
+/* x.amax(dim=(-2,-1)) -> out[n*out_stride + out_off + c]  (classification.py:46-49) */
+int cvpce_global_max_nhwc_bf16(const void* in, float* out, int N, int HW, int C, int out_stride, int out_off,
+                               void* stream);
+/* desc / norm(desc).clamp(min=eps) (classification.py:51); out_bf16 optional */
+int cvpce_l2_normalize_f32(const float* in, float* out, void* out_bf16, int B, int D, float eps, void* stream);
+
+/* GeneralizedRCNNTransform for one image (normalise, bilinear resize to (h,w), zero pad to
+ * (Hp,Wp)) -> NHWC8 bf16 slot of the batch.  img: f32 CHW [3][H0][W0].  mean3/std3 [host]. */
+int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
+                        const float* mean3, const float* std3, void* stream);
+
+/* production.py:20 + datautils.py:234-239: crop boxes (xyxy f32, truncated like .to(long)) from the
+ * original image, pad to square with 0.5, bilinear resize to SxS.  Boxes p >= *count_dev are skipped
+ * (count_dev may be NULL).  mode 0: f32 NCHW in [0,1]; mode 1: NHWC8 bf16 with scale_to_tanh
+ * (utils.py:280) and the MACVGG normalisation (classification.py:41-44) fused.  mean3/std3 [host]. */
+int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
+                      int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream);
+/* (B,3,S,S) f32 NCHW -> NHWC8 bf16: optional x*2-1, then (x-mean)/std (Classifier.classify / build_index input) */
+int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int to_tanh, const float* mean3,
+                           const float* std3, void* stream);
+
+/* RetinaNet.postprocess_detections + batched_nms + transform.postprocess (torchvision 0.9) and the
+ * confidence-prefix count of production.py:15.  logits/regs/gh/gw/stride_* are [host] arrays of L
+ * entries; logits[l] -> f32 [N][gh*gw*A*K], regs[l] -> f32 [N][gh*gw*A][4] (NHWC conv outputs).
+ * base_anchors f32 [L][A][4]; image_hw int [N][2] resized sizes; ratios f32 [N][2] (orig/resized h,w).
+ * Outputs: boxes [N][dpi][4] (original pixels), scores [N][dpi], labels i64 [N][dpi], count [N],
+ * conf_count [N] = #scores > conf_thresh. */
+size_t cvpce_detect_workspace_bytes(int N, int L, int topk);
+int cvpce_detect_postprocess(const float* const* logits, const float* const* regs, const int* gh, const int* gw,
+                             const int* stride_h, const int* stride_w, const float* base_anchors,
+                             const int* image_hw, const float* ratios, int L, int N, int A, int K, int topk,
+                             float score_thresh, float nms_thresh, float xform_clip, int detections_per_img,
+                             float conf_thresh, void* workspace, size_t workspace_bytes, float* out_boxes,
+                             float* out_scores, long long* out_labels, int* out_count, int* out_conf_count,
+                             void* stream);
+
+/* classification.py:87-95: nearest_neighbors(anchors=gallery, queries, k) -> (Q,k) int64, ascending
+ * cosine distance, ties to the lower index.  Rows bf16 (is_f32 = 0) or f32 (is_f32 = 1), D % 64 == 0;
+ * norms from cvpce_row_norms (already clamped at eps). */
+int cvpce_row_norms(const void* x, float* out, int rows, int D, int is_f32, float eps, void* stream);
+size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k);
+int cvpce_match_topk(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
+                     int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
+                     long long* out_idx, float* out_dist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

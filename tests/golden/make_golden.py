@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the reference's own pure-torch code.
+
+DEV-ONLY TOOL: runs in the build container where /root/reference is mounted.
+It never travels to the GPU box and nothing in tests/, bench.py or the package
+imports it.  The committed products are the small `*.pt` fixtures next to this
+file (data only: inputs, weights, expected outputs).
+
+torchvision / cv2 / ray / pix2pix are absent here, so every
+hot-path module of the reference fails on import.  The members we capture are
+pure torch; we therefore place inert stand-ins for the absent third-party
+modules in sys.modules *for the import only* (base classes -> nn.Module).  No
+stand-in is ever *executed* to make a golden value, with one exception that is
+pinned by the reference's own KATs: `box_iou` (test/metrics_test.py:23-59).
+
+Captured:
+  gaussian_head.pt   GaussianLayer + GaussianSubnet (cvpce/models/proposals.py:51-107)
+                     eval() with non-trivial BN running stats, tanh in {False, True}
+  nearest.pt         distance / nearest_neighbors (cvpce/models/classification.py:87-95)
+                     incl. the reference KAT (test/models/classification_test.py:8-25)
+  metrics.pt         metrics KAT inputs + outputs of the reference implementation
+                     (cvpce/metrics.py:11-138, test/metrics_test.py:5-21,116-128)
+"""
+import os
+import sys
+import types
+from math import sqrt
+
+import torch
+from torch import nn
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_modules():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Base(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    def box_iou(a, b):  # pinned by test/metrics_test.py:23-59 (checked below)
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(a[:, None, :2], b[:, :2])
+        rb = torch.min(a[:, None, 2:], b[:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, :, 0] * wh[:, :, 1]
+        return inter / (area_a[:, None] + area_b - inter)
+
+    tv = mod('torchvision')
+    tv.models = mod('torchvision.models', utils=mod('torchvision.models.utils'),
+                    vgg=mod('torchvision.models.vgg'), resnet=mod('torchvision.models.resnet'))
+    det = mod('torchvision.models.detection', RetinaNet=_Base)
+    mod('torchvision.models.detection.backbone_utils', BackboneWithFPN=_Base)
+    tv.ops = mod('torchvision.ops', box_iou=box_iou)
+    mod('torchvision.ops.feature_pyramid_network', ExtraFPNBlock=_Base, LastLevelP6P7=_Base)
+    mod('torchvision.ops.misc', FrozenBatchNorm2d=_Base)
+    tv.transforms = mod('torchvision.transforms', functional=mod('torchvision.transforms.functional'))
+    tv.utils = mod('torchvision.utils')
+    tv.models.detection = det
+    for name in ('cv2', 'squarify', 'skimage', 'skimage.draw', 'ray', 'ray.tune'):
+        mod(name)
+    mod('skimage.segmentation', flood=None)
+    mod('skimage.filters', sobel=None)
+    # un-vendored pix2pix submodule (cvpce/models/classification.py:8)
+    mod('cvpce.models.pix2pix')
+    mod('cvpce.models.pix2pix.models', networks=mod('cvpce.models.pix2pix.models.networks'))
+
+
+def main():
+    _stub_modules()
+    sys.path.insert(0, REF)
+    import matplotlib
+    matplotlib.use('Agg')
+    from cvpce.models import proposals as ref_prop
+    from cvpce.models import classification as ref_cls
+    from cvpce import metrics as ref_metrics
+
+    # ---- 1. Gaussian head ------------------------------------------------
+    out = {}
+    for tanh in (False, True):
+        torch.manual_seed(11 + int(tanh))
+        c_ch, p_ch = 16, 16
+        layer = ref_prop.GaussianLayer(c_ch, p_ch)
+        subnet = ref_prop.GaussianSubnet(p_ch // 4, tanh)
+        for m in list(layer.modules()) + list(subnet.modules()):
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.2)
+            if isinstance(m, nn.Conv2d):
+                m.bias.data.normal_(0, 0.1)
+        layer.eval(); subnet.eval()
+        c2 = torch.randn(2, c_ch, 12, 20)
+        p3 = torch.randn(2, p_ch, 6, 10)
+        with torch.no_grad():
+            feat = layer(c2, p3)
+            g = subnet(feat)
+        out[f'tanh_{tanh}'] = {
+            'layer_state': {k: v.clone() for k, v in layer.state_dict().items()},
+            'subnet_state': {k: v.clone() for k, v in subnet.state_dict().items()},
+            'c2': c2, 'p3': p3, 'features': feat, 'gaussians': g,
+        }
+    torch.save(out, os.path.join(HERE, 'gaussian_head.pt'))
+
+    # ---- 2. distance / nearest_neighbors ----------------------------------
+    anchors = torch.tensor([
+        [1, 0, 0],
+        [1 / sqrt(3), 1 / sqrt(3), 1 / sqrt(3)],
+        [-1 / sqrt(3), -1 / sqrt(3), -1 / sqrt(3)],
+        [-1, 0, 0],
+        [1 / sqrt(2), 0, 1 / sqrt(2)],
+        [-1 / sqrt(2), 0, -1 / sqrt(2)],
+    ], dtype=torch.float)
+    queries = torch.tensor([
+        [1 / sqrt(1.01), 0.1 / sqrt(1.01), 0],
+        [0.9 / sqrt(2.02), 0, 1.1 / sqrt(2.02)],
+        [-1, 0, 0],
+        [1, 0, 0],
+        [1 / sqrt(3), 1 / sqrt(3), 1 / sqrt(3)],
+        [-1.1 / sqrt(2.02), 0, -0.9 / sqrt(2.02)],
+        [-1, 0, 0],
+    ])
+    kat_expected = torch.tensor([0, 4, 3, 0, 1, 5, 3])
+    import warnings
+    warnings.simplefilter('ignore')
+    got = ref_cls.nearest_neighbors(anchors, queries)[:, 0]
+    assert kat_expected.equal(got), 'reference KAT failed under stubs'
+    cases = []
+    for seed, (q, a, d, k) in enumerate([(7, 50, 16, 1), (16, 120, 64, 4), (33, 200, 256, 4), (24, 150, 1024, 1), (20, 97, 1024, 8)]):
+        g = torch.Generator().manual_seed(100 + seed)
+        A = torch.nn.functional.normalize(torch.randn(a, d, generator=g), dim=1)
+        Q = torch.nn.functional.normalize(torch.randn(q, d, generator=g), dim=1)
+        dist = ref_cls.distance(A[None, :, :].expand(q, a, d), Q[:, None, :].expand(q, a, d), dim=-1)
+        idx = ref_cls.nearest_neighbors(A, Q, k)
+        # keep only tie-free cases (gap between consecutive sorted distances of the first k+1)
+        srt = dist.sort(dim=-1).values[:, :k + 1]
+        gap = (srt[:, 1:] - srt[:, :-1]).min().item()
+        cases.append({'anchors': A, 'queries': Q, 'k': k, 'indices': idx, 'distances': dist, 'min_gap': gap})
+    torch.save({'kat': {'anchors': anchors, 'queries': queries, 'expected': kat_expected}, 'cases': cases},
+               os.path.join(HERE, 'nearest.pt'))
+
+    # ---- 3. metrics ------------------------------------------------------
+    T = [
+        torch.tensor([[0, 0, 1, 1], [1, 0, 2, 1], [1, 1, 2, 2]], dtype=torch.float),
+        torch.tensor([[1, 1, 2, 2], [3, 1, 4, 2], [5, 1, 6, 2], [7, 1, 8, 2]], dtype=torch.float),
+        torch.tensor([[0, 0, 5, 5], [5, 5, 10, 10]], dtype=torch.float),
+    ]
+    P = [
+        torch.tensor([[0, 0, .9, .9], [1.1, 0.1, 1.9, 0.9], [0, 0, 1, 1], [0.9, 0.9, 2.1, 2.1], [3, 3, 4, 4]], dtype=torch.float),
+        torch.tensor([[1, 0, 2, 1], [1, 1, 2, 2], [5, 1, 6, 2], [7, 1.1, 8, 1.9], [9, 9, 10, 10]], dtype=torch.float),
+        torch.tensor([[0, 0, 1, 1], [1, 1, 3, 3], [0.5, 0.5, 4.5, 4.5], [0, 0, 6, 6], [6, 6, 9, 9]], dtype=torch.float),
+    ]
+    C = [
+        torch.tensor([1, 0.8, 0.6, 0.4, 0.2], dtype=torch.float),
+        torch.tensor([0.9, 0.8, 0.7, 0.65, 0.5], dtype=torch.float),
+        torch.tensor([0.85, 0.6, 0.4, 0.2, 0.1], dtype=torch.float),
+    ]
+    # validate the box_iou stand-in against the reference's own expected values
+    ious, idx = ref_metrics.iou_matrices(T[2], P[2])
+    exp = torch.tensor([[0.04, 0], [0.16, 0], [0.64, 0], [(5 * 5) / (6 * 6), 1 / (5 * 5 + 6 * 6 - 1)], [0.36, 0]])
+    assert exp.allclose(ious)
+    res = ref_metrics.calculate_metrics(T, P, C)
+    g = torch.Generator().manual_seed(5)
+    rnd = []
+    for n_img in (3, 5):
+        tg, pr, cf = [], [], []
+        for _ in range(n_img):
+            nt = int(torch.randint(1, 12, (1,), generator=g))
+            xy = torch.rand(nt, 2, generator=g) * 50
+            wh = torch.rand(nt, 2, generator=g) * 20 + 5
+            t = torch.cat([xy, xy + wh], 1)
+            npred = int(torch.randint(1, 20, (1,), generator=g))
+            pick = torch.randint(0, nt, (npred,), generator=g)
+            p = t[pick] + torch.randn(npred, 4, generator=g) * 3
+            p[:, 2:] = torch.max(p[:, 2:], p[:, :2] + 1)
+            tg.append(t); pr.append(p); cf.append(torch.rand(npred, generator=g))
+        r = ref_metrics.calculate_metrics(tg, pr, cf, iou_thresholds=(0.5, 0.75))
+        rnd.append({'targets': tg, 'predictions': pr, 'confidences': cf,
+                    'result': {t: {k: v for k, v in d.items() if k != 'raw'} | {'raw': d['raw']} for t, d in r.items()}})
+    torch.save({'targets': T, 'predictions': P, 'confidences': C,
+                'kat_result': {k: v for k, v in res[0.5].items()}, 'random': rnd},
+               os.path.join(HERE, 'metrics.pt'))
+    print('golden fixtures written to', HERE)
+
+
+if __name__ == '__main__':
+    main()
