@@ -253,8 +253,8 @@ extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const flo
                                       int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
                                       int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
                                       void* stream) {
-    if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (N <= 0) return CVPCE_OK;
+    if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (Cin % 8 != 0 || K_pad % 64 != 0 || Cout_pad % 128 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
     if (K_pad < KH * KW * Cin) return CVPCE_ERR_ARG;
     if (!out_f32 && (Cout % 4 != 0)) return CVPCE_ERR_ARG;

@@ -369,7 +369,7 @@ extern "C" size_t cvpce_detect_workspace_bytes(int N, int L, int topk) {
     b += (size_t)N * Tmax * (4 + 1 + 1 + 1) * 4;       // sorted boxes/scores/labels/off
     b += (size_t)N * 4;                                // s_total
     b += (size_t)N * Tmax * words * 8;                 // mask
-    return b + 1024;
+    return b + 16 * 256;   // every sub-allocation is rounded up to 256 B
 }
 
 extern "C" int cvpce_detect_postprocess(const float* const* logits, const float* const* regs, const int* gh,

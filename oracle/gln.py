@@ -215,15 +215,18 @@ def clip_boxes(boxes, hw):
     return torch.stack((x[:, 0], y[:, 0], x[:, 1], y[:, 1]), dim=1)
 
 
-def nms(boxes, scores, thresh):
+def nms(boxes, scores, thresh, order_key=None):
     """torchvision nms: greedy, score-descending, suppress IoU > thresh (strict).
 
-    Ties in `scores` are undefined in the reference (unstable sort); the oracle
-    and the HIP path both resolve them lowest-index-first (stable sort).
+    Ties in `scores` are undefined in the reference (unstable sort).  The oracle
+    and the HIP path both refine the order deterministically: by `order_key`
+    (the fp32 logit, a monotone refinement of the sigmoid score -- distinct
+    logits may round to one score) and then lowest-index-first (stable sort).
+    Any such order is one the reference itself could produce.
     """
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
-    order = torch.sort(scores, descending=True, stable=True).indices
+    order = torch.sort(scores if order_key is None else order_key, descending=True, stable=True).indices
     b = boxes[order]
     areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
     n = b.shape[0]
@@ -245,33 +248,34 @@ def nms(boxes, scores, thresh):
     return order[torch.tensor(keep, dtype=torch.int64)]
 
 
-def topk_stable(scores, k):
-    """torch.topk with the tie rule fixed to lowest-index-first."""
-    order = torch.sort(scores, descending=True, stable=True).indices[:k]
-    return scores[order], order
+def topk_stable(keys, k):
+    """torch.topk with the tie rule fixed: by key (logit) descending, then lowest index."""
+    return torch.sort(keys, descending=True, stable=True).indices[:k]
 
 
 def postprocess_image(cls_levels, reg_levels, anchor_levels, image_hw, detections_per_img,
                       score_thresh=SCORE_THRESH, nms_thresh=NMS_THRESH, topk=TOPK_CANDIDATES):
     """One image: per-level lists of (HWA,K) logits / (HWA,4) regs / (HWA,4) anchors."""
-    boxes, scores, labels = [], [], []
+    boxes, scores, labels, keys = [], [], [], []
     for logits, reg, anchors in zip(cls_levels, reg_levels, anchor_levels):
         num_classes = logits.shape[-1]
-        s = torch.sigmoid(logits).flatten()
+        lg = logits.flatten()
+        s = torch.sigmoid(lg)
         keep = s > score_thresh
         cand = torch.where(keep)[0]
-        s, idx = topk_stable(s[keep], min(topk, cand.numel()))
+        idx = topk_stable(lg[keep], min(topk, cand.numel()))
         cand = cand[idx]
         a_idx = torch.div(cand, num_classes, rounding_mode='floor')
         labels.append(cand % num_classes)
         b = decode_single(reg[a_idx], anchors[a_idx])
         boxes.append(clip_boxes(b, image_hw))
-        scores.append(s)
-    boxes, scores, labels = torch.cat(boxes), torch.cat(scores), torch.cat(labels)
+        scores.append(s[cand])
+        keys.append(lg[cand])
+    boxes, scores, labels, keys = torch.cat(boxes), torch.cat(scores), torch.cat(labels), torch.cat(keys)
     # batched_nms: offsets = label * (max_coord + 1); num_classes == 1 -> all zero
     if boxes.numel():
         offs = labels.to(boxes) * (boxes.max() + 1)
-        keep = nms(boxes + offs[:, None], scores, nms_thresh)
+        keep = nms(boxes + offs[:, None], scores, nms_thresh, order_key=keys)
     else:
         keep = torch.empty((0,), dtype=torch.int64)
     keep = keep[:detections_per_img]

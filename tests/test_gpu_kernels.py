@@ -1,0 +1,318 @@
+"""Kernel-level parity: each HIP entry point of include/cvpce_amd.h (called through
+cvpce_amd.ops -> ctypes -> C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances: convolutions compute in bf16 x bf16 -> fp32 accumulate; the oracle is fed the SAME
+bf16-rounded operands, so the only differences are fp32 summation order (+ one bf16 rounding of
+the output when the output is bf16).  Index outputs (top-k, NMS, nearest neighbour) are exact.
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def r16(t):
+    return t.to(BF).to(torch.float32)
+
+
+def nhwc(x):
+    """(N,C,H,W) f32 -> NHWC bf16 with C padded to 8"""
+    n, c, h, w = x.shape
+    cp = (c + 7) // 8 * 8
+    out = torch.zeros(n, h, w, cp, dtype=BF)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(BF)
+    return out
+
+
+def nchw(y):
+    return y.float().permute(0, 3, 1, 2).cpu()
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-6)).item()
+
+
+CONV_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, pad, opts
+    ('vgg_first', 2, 3, 40, 36, 64, 3, 1, 1, {}),
+    ('stem7x7', 2, 3, 67, 45, 64, 7, 2, 3, {}),
+    ('1x1', 2, 64, 25, 31, 256, 1, 1, 0, {}),
+    ('3x3_s1', 1, 128, 33, 29, 128, 3, 1, 1, {}),
+    ('3x3_s2', 2, 64, 26, 30, 64, 3, 2, 1, {}),
+    ('1x1_s2_ds', 1, 256, 20, 20, 512, 1, 2, 0, {'act': 0}),
+    ('cin32', 1, 32, 30, 30, 32, 3, 1, 1, {}),
+    ('cin16_1x1', 1, 16, 30, 31, 16, 1, 1, 0, {}),
+    ('residual', 2, 64, 18, 22, 256, 1, 1, 0, {'res': 'same'}),
+    ('res_upsample', 2, 64, 20, 24, 256, 1, 1, 0, {'res': 'up', 'act': 0}),
+    ('in_upsample', 1, 64, 12, 14, 32, 3, 1, 1, {'in_up': 1}),
+    ('cls_f32', 2, 256, 13, 13, 9, 3, 1, 1, {'f32': True, 'act': 0}),
+    ('reg_f32', 1, 256, 7, 7, 36, 3, 1, 1, {'f32': True, 'act': 0}),
+    ('gauss_out', 1, 16, 40, 40, 1, 1, 1, 0, {'f32': True, 'act': 1}),
+    ('gauss_tanh', 1, 16, 40, 40, 1, 1, 1, 0, {'f32': True, 'act': 2}),
+    ('deep_k', 1, 512, 9, 9, 512, 3, 1, 1, {}),
+    ('ragged_m', 3, 64, 5, 3, 192, 3, 1, 1, {}),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_parity(cuda, case):
+    from cvpce_amd import ops
+    name, n, cin, h, w, cout, k, stride, pad, o = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g) * 0.1
+    act = o.get('act', 1)
+    in_up = o.get('in_up', 0)
+    pc = ops.PackedConv(wgt, bias, stride, pad, device=cuda)
+    xin = r16(x)
+    xl = F.interpolate(xin, scale_factor=2.0, mode='nearest') if in_up else xin
+    ref = F.conv2d(xl, r16(wgt), bias, stride=stride, padding=pad)
+    res_dev = None
+    if o.get('res') == 'same':
+        res = r16(torch.randn(ref.shape, generator=g))
+        ref = ref + res
+        res_dev = nhwc(res).to(cuda)
+    elif o.get('res') == 'up':
+        res = r16(torch.randn(n, cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g))
+        ref = ref + F.interpolate(res, size=ref.shape[-2:], mode='nearest')
+        res_dev = nhwc(res).to(cuda)
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = torch.tanh(ref)
+    y = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev, in_up_shift=in_up)
+    torch.cuda.synchronize()
+    got = nchw(y)
+    assert got.shape == ref.shape
+    tol = 2e-4 if o.get('f32') else 1e-2   # bf16 output rounding = 2^-8 relative
+    assert rel_err(got, ref) < tol, (name, rel_err(got, ref))
+
+
+def test_conv2d_rejects_bad_args(cuda):
+    from cvpce_amd import ops
+    pc = ops.PackedConv(torch.randn(64, 64, 3, 3), None, 1, 1, device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 8, 8, 64, dtype=BF), pc)  # CPU tensor: loud, no fallback
+    pc9 = ops.PackedConv(torch.randn(9, 64, 3, 3), None, 1, 1, device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 8, 8, 64, dtype=BF, device=cuda), pc9, out_f32=False)  # Cout % 4 != 0 needs f32 out
+
+
+def test_conv2d_empty_batch(cuda):
+    from cvpce_amd import ops
+    pc = ops.PackedConv(torch.randn(64, 64, 3, 3), None, 1, 1, device=cuda)
+    y = ops.conv2d(torch.zeros(0, 8, 8, 64, dtype=BF, device=cuda), pc)
+    assert y.shape == (0, 8, 8, 64)
+
+
+@pytest.mark.parametrize('k,stride,pad,h,w', [(2, 2, 0, 16, 20), (3, 2, 1, 17, 23), (2, 2, 0, 7, 9)])
+def test_maxpool_parity(cuda, k, stride, pad, h, w):
+    from cvpce_amd import ops
+    x = r16(torch.randn(2, 24, h, w, generator=torch.Generator().manual_seed(3)))
+    ref = F.max_pool2d(x, k, stride, pad)
+    got = nchw(ops.maxpool2d(nhwc(x).to(cuda), k, stride, pad))
+    assert torch.equal(got, ref)
+
+
+def test_relu_globalmax_l2norm(cuda):
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = r16(torch.randn(3, 72, 9, 11, generator=g))
+    assert torch.equal(nchw(ops.relu(nhwc(x).to(cuda))), F.relu(x))
+    desc = torch.full((3, 100), -7.0, device=cuda)
+    ops.global_max_into(nhwc(x).to(cuda), desc, 20)
+    assert torch.equal(desc[:, 20:92].cpu(), x.amax(dim=(-2, -1)))
+    assert (desc[:, :20] == -7).all() and (desc[:, 92:] == -7).all()
+    d = torch.rand(5, 1024, generator=g)
+    d[3] = 0
+    out, out_bf = ops.l2_normalize(d.to(cuda), 1e-8, want_bf16=True)
+    ref = d / torch.linalg.norm(d, dim=1, keepdim=True).clamp(min=1e-8)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-7)
+    assert torch.equal(out_bf.cpu(), out.cpu().to(BF))
+
+
+@pytest.mark.parametrize('h0,w0', [(640, 640), (2048, 2048), (300, 517), (1200, 700)])
+def test_transform_parity(cuda, h0, w0):
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    from oracle import gln as og
+    img = torch.rand(3, h0, w0, generator=torch.Generator().manual_seed(h0))
+    ref = og.transform_one(img)
+    h, w = P.resized_hw(h0, w0)
+    assert (h, w) == tuple(ref.shape[-2:]) == og.resized_size(h0, w0)
+    hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    batch = torch.full((1, hp, wp, 8), 9.0, dtype=BF, device=cuda)
+    ops.gln_transform_into(img.to(cuda), batch, 0, h, w, P.IMAGE_MEAN, P.IMAGE_STD)
+    got = batch[0].float().cpu()
+    assert (got[..., 3:] == 0).all() and (got[h:] == 0).all() and (got[:, w:] == 0).all()
+    # fp32 interpolation identical up to rounding; compare after the same bf16 rounding
+    diff = (got[:h, :w, :3].permute(2, 0, 1) - ref).abs().max().item()
+    assert diff < 2e-2, diff   # bf16 ulp at |x| <= 2.7 is 1.6e-2
+    frac_exact = (got[:h, :w, :3].permute(2, 0, 1) == r16(ref)).float().mean().item()
+    assert frac_exact > 0.99, frac_exact
+
+
+def test_crop_resize_parity(cuda):
+    from cvpce_amd import ops
+    from cvpce_amd.models.classification import TANH_MEAN, TANH_STD
+    from oracle import crop as ocrop, macvgg as ovgg
+    img = torch.rand(3, 300, 400, generator=torch.Generator().manual_seed(9))
+    boxes = torch.tensor([[10.7, 20.2, 110.9, 80.5],     # wide
+                          [0.0, 0.0, 400.0, 300.0],      # whole image
+                          [395.2, 5.0, 400.0, 299.9],    # thin, tall
+                          [50.0, 60.0, 51.9, 61.2],      # 1x1 pixel
+                          [100.3, 100.3, 356.3, 356.3],  # clipped by the image bottom (y2 > H)
+                          [7.0, 9.0, 263.0, 265.0]])     # exactly 256x256 (identity resize)
+    ref = ocrop.crop_boxes(img, boxes)
+    got = ops.crop_resize(img.to(cuda), boxes.to(cuda), 256, mode=0).cpu()
+    torch.testing.assert_close(got, ref, rtol=0, atol=2e-6)
+    packed = ops.crop_resize(img.to(cuda), boxes.to(cuda), 256, mode=1, mean=TANH_MEAN, std=TANH_STD).float().cpu()
+    refp = ovgg.normalize_tanh(ocrop.scale_to_tanh(ref)).permute(0, 2, 3, 1)
+    assert (packed[..., 3:] == 0).all()
+    assert (packed[..., :3] - refp).abs().max() < 2e-2
+    # the API-level pack kernel must agree bit-for-bit with the fused crop path
+    packed2 = ops.pack_embed_input(got.to(cuda), True, TANH_MEAN, TANH_STD).float().cpu()
+    assert torch.equal(packed2, packed)
+    # device-side count: rows >= count are not touched
+    out = torch.full((6, 256, 256, 8), 5.0, dtype=BF, device=cuda)
+    cnt = torch.tensor([2], dtype=torch.int32, device=cuda)
+    ops.crop_resize(img.to(cuda), boxes.to(cuda), 256, mode=1, mean=TANH_MEAN, std=TANH_STD, count=cnt, out=out)
+    assert (out[2:] == 5).all() and torch.equal(out[:2].float().cpu(), packed[:2])
+
+
+def _random_head_outputs(n, grids, a, k, seed, spread=2.0, bias=-1.0):
+    g = torch.Generator().manual_seed(seed)
+    cls = [torch.randn(n, gh * gw * a * k, generator=g) * spread + bias for gh, gw in grids]
+    reg = [torch.randn(n, gh * gw * a, 4, generator=g) * 0.5 for gh, gw in grids]
+    return cls, reg
+
+
+@pytest.mark.parametrize('dpi,seed,bias', [(1000, 0, -1.0), (200, 1, 1.0), (300, 2, -4.5)])
+def test_detect_postprocess_parity(cuda, dpi, seed, bias):
+    """K6-K8 against the oracle on identical fp32 logits: kept sets and order identical."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    from oracle import gln as og
+    n = 2
+    padded = (800, 832)
+    grids = [(100, 104), (50, 52), (25, 26), (13, 13), (7, 7)]
+    cls, reg = _random_head_outputs(n, grids, 9, 1, seed, bias=bias)
+    resized = [(800, 810), (790, 832)]
+    original = [(2048, 2073), (1000, 1053)]
+    anchors = og.grid_anchors(padded, grids)
+    strides = [(padded[0] // gh, padded[1] // gw) for gh, gw in grids]
+    base = P._base_anchors()
+    assert torch.equal(base, torch.stack([og.base_anchors(s) for s in og.ANCHOR_SIZES]))
+    image_hw = torch.tensor(resized, dtype=torch.int32)
+    ratios = torch.stack([torch.tensor(o, dtype=torch.float32) / torch.tensor(r, dtype=torch.float32)
+                          for o, r in zip(original, resized)])
+    boxes, scores, labels, count, conf = ops.detect_postprocess(
+        [c.to(cuda) for c in cls], [r.to(cuda) for r in reg], grids, strides, base.to(cuda), image_hw.to(cuda),
+        ratios.to(cuda), 9, 1, og.TOPK_CANDIDATES, og.SCORE_THRESH, og.NMS_THRESH, og.BBOX_XFORM_CLIP, dpi, 0.5)
+    torch.cuda.synchronize()
+    for i in range(n):
+        # oracle with the documented tie refinement: order by logit (monotone in score), then index
+        b, s, l = og.postprocess_image([c[i][:, None] for c in cls], [r[i] for r in reg], anchors, resized[i], dpi)
+        b = og.resize_boxes(b, resized[i], original[i])
+        c = int(count[i])
+        assert c == len(b), (c, len(b))
+        torch.testing.assert_close(scores[i, :c].cpu(), s, rtol=0, atol=1e-6)
+        torch.testing.assert_close(boxes[i, :c].cpu(), b, rtol=1e-5, atol=2e-3)
+        assert (labels[i, :c] == 0).all()
+        assert int(conf[i]) == int((s > 0.5).sum())
+        assert (scores[i, :c - 1] >= scores[i, 1:c]).all()
+
+
+def test_detect_postprocess_no_candidates(cuda):
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    from oracle import gln as og
+    grids = [(4, 4), (2, 2)]
+    cls = [torch.full((1, gh * gw * 9), -10.0) for gh, gw in grids]
+    reg = [torch.zeros(1, gh * gw * 9, 4) for gh, gw in grids]
+    out = ops.detect_postprocess([c.to(cuda) for c in cls], [r.to(cuda) for r in reg], grids, [(8, 8), (16, 16)],
+                                 P._base_anchors()[:2].contiguous().to(cuda), torch.tensor([[32, 32]], dtype=torch.int32).to(cuda),
+                                 torch.ones(1, 2).to(cuda), 9, 1, 1000, 0.05, 0.5, og.BBOX_XFORM_CLIP, 100, 0.5)
+    assert int(out[3][0]) == 0 and int(out[4][0]) == 0
+
+
+def test_nms_properties_full_size(cuda):
+    """Full-size (800x800, 120 087 anchors x 4 images) run checked through size-independent properties."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    from oracle import gln as og
+    n = 4
+    grids = [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)]
+    cls, reg = _random_head_outputs(n, grids, 9, 1, 11, bias=1.0)
+    strides = [(800 // gh, 800 // gw) for gh, gw in grids]
+    image_hw = torch.tensor([[800, 800]] * n, dtype=torch.int32)
+    ratios = torch.full((n, 2), 2.56)
+    boxes, scores, labels, count, conf = ops.detect_postprocess(
+        [c.to(cuda) for c in cls], [r.to(cuda) for r in reg], grids, strides, P._base_anchors().to(cuda),
+        image_hw.to(cuda), ratios.to(cuda), 9, 1, 1000, 0.05, 0.5, og.BBOX_XFORM_CLIP, 1000, 0.5)
+    for i in range(n):
+        c = int(count[i])
+        assert 0 < c <= 1000
+        b, s = boxes[i, :c].cpu(), scores[i, :c].cpu()
+        assert (s[:-1] >= s[1:]).all() and (s > 0.05).all()
+        assert (b[:, 0] >= 0).all() and (b[:, 2] <= 2048.0 + 1e-3).all() and (b[:, 2] >= b[:, 0]).all()
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(b[:, None, :2], b[:, :2]); rb = torch.min(b[:, None, 2:], b[:, 2:])
+        inter = (rb - lt).clamp(min=0).prod(dim=2)
+        iou = torch.nan_to_num(inter / (area[:, None] + area - inter), nan=0.0)   # 0/0 for clipped-to-empty boxes
+        iou.fill_diagonal_(0)
+        assert iou.max() <= 0.5 + 1e-5, iou.max()   # no kept pair overlaps more than the NMS threshold
+        assert int(conf[i]) == int((s > 0.5).sum())
+
+
+def test_match_reference_kat_and_golden(cuda, golden_dir):
+    from cvpce_amd.models import classification as C
+    from oracle import match as omatch
+    gold = torch.load(os.path.join(golden_dir, 'nearest.pt'), weights_only=False)
+    kat = gold['kat']
+    got = C.nearest_neighbors(kat['anchors'].to(cuda), kat['queries'].to(cuda))[:, 0].cpu()
+    assert kat['expected'].equal(got)                       # test/models/classification_test.py:8-25
+    for case in gold['cases']:
+        a, q, k = case['anchors'], case['queries'], case['k']
+        got = C.nearest_neighbors(a.to(cuda), q.to(cuda), k).cpu()
+        assert got.dtype == torch.int64 and got.shape == (len(q), k)
+        srt = case['distances'].sort(dim=-1).values[:, :k + 1]
+        safe = (srt[:, 1:] - srt[:, :-1]).min(dim=1).values > 1e-5
+        assert got[safe].equal(case['indices'][safe]), 'fp32 path must be index-exact on tie-free rows'
+        # the remaining rows: same SET of distances within fp32 rounding
+        d = case['distances']
+        assert (d.gather(1, got) - d.gather(1, case['indices'])).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('qn,gn,d,k', [(200, 1000, 1024, 1), (37, 3200, 1024, 4), (130, 129, 512, 3), (5, 10000, 512, 1)])
+def test_match_parity(cuda, dtype, qn, gn, d, k):
+    from cvpce_amd import ops
+    from oracle import match as omatch
+    g = torch.Generator().manual_seed(qn + gn)
+    G = F.normalize(torch.rand(gn, d, generator=g), dim=1)     # non-negative like MAC descriptors
+    Q = F.normalize(torch.rand(qn, d, generator=g), dim=1)
+    Gd, Qd = G.to(dtype), Q.to(dtype)
+    idx, dist = ops.match_topk(Qd.to(cuda), Gd.to(cuda), k, return_distance=True)
+    ref_d = omatch.cosine_distance_matrix(Gd.float(), Qd.float())    # oracle on the same (rounded) operands
+    ref_idx = torch.sort(ref_d, dim=-1, stable=True).indices[:, :k]
+    srt = ref_d.sort(dim=-1).values[:, :k + 1]
+    safe = (srt[:, 1:] - srt[:, :-1]).min(dim=1).values > 2e-6
+    assert safe.float().mean() > 0.9
+    assert idx.cpu()[safe].equal(ref_idx[safe])
+    torch.testing.assert_close(dist.cpu(), ref_d.gather(1, idx.cpu()), rtol=0, atol=2e-6)
+
+
+def test_match_ties_lowest_index(cuda):
+    from cvpce_amd import ops
+    G = torch.zeros(300, 64); G[:, 0] = 1.0       # all gallery rows identical -> all distances tie
+    Q = torch.zeros(3, 64); Q[:, 0] = 1.0
+    idx = ops.match_topk(Q.to(cuda), G.to(cuda), 5).cpu()
+    assert idx.equal(torch.arange(5).expand(3, 5))
