@@ -248,17 +248,7 @@ class GLNEngine:
         self.inner = [P(m) for m in fpn.inner_blocks]
         self.outer = [P(m) for m in fpn.layer_blocks]
         self.p6, self.p7 = P(fpn.extra_blocks.p6), P(fpn.extra_blocks.p7)
-        gl = model.backbone.gaussian_layer
-
-        def fold_bn(blk):
-            bn = blk.norm
-            s = bn.weight * (bn.running_var + bn.eps).rsqrt()
-            return P(blk.conv, scale=s, shift=bn.bias - bn.running_mean * s)
-
-        self.g_lateral = P(gl.lateral)
-        self.g_block1, self.g_block2 = fold_bn(gl.block1), fold_bn(gl.block2)
-        self.g_subnet = [P(b.conv) for b in model.backbone.gaussian_subnet.blocks]
-        self.tanh = model.backbone.gaussian_subnet.tanh
+        self.pack_gaussian(model.backbone.gaussian_layer, model.backbone.gaussian_subnet, device)
         ch, rh = model.head.classification_head, model.head.regression_head
         self.cls_tower = [P(ch.conv[i]) for i in (0, 2, 4, 6)]
         self.cls_out = P(ch.cls_logits)
@@ -267,6 +257,20 @@ class GLNEngine:
         self.base_anchors = _base_anchors().to(device)
         self.num_anchors = self.base_anchors.shape[1]
         self.device = device
+
+    def pack_gaussian(self, gl, subnet, device):
+        """Gaussian branch weights (proposals.py:65-107): eval-mode BatchNorm folded into block1/block2."""
+        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, **kw)
+
+        def fold_bn(blk):
+            bn = blk.norm
+            s = bn.weight * (bn.running_var + bn.eps).rsqrt()
+            return P(blk.conv, scale=s, shift=bn.bias - bn.running_mean * s)
+
+        self.g_lateral = P(gl.lateral)
+        self.g_block1, self.g_block2 = fold_bn(gl.block1), fold_bn(gl.block2)
+        self.g_subnet = [P(b.conv) for b in subnet.blocks]
+        self.tanh = subnet.tanh
 
     # -- stages ---------------------------------------------------------------
     def transform(self, images):
