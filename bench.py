@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: shelf images/sec end-to-end (detect + RoI-crop + embed + match) on MI355X.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one
+rank per GPU over RCCL).  One "step" = one pass of the whole hot path over one batch of
+`--images-per-gpu` synthetic SKU-110K-shaped shelf images per GPU (weak scaling), inputs resident in
+HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--images-per-gpu', type=int, default=8)
+    ap.add_argument('--image-size', type=int, default=2048)
+    ap.add_argument('--gallery', type=int, default=3200)
+    ap.add_argument('--detections-per-img', type=int, default=200)
+    ap.add_argument('--match-dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
+    """The oracle (a port: plain fp32 torch CPU ops restating the reference) on a bounded sample of the
+    same workload, on this box's host cores: 1 shelf image through the detector, 4 crops through the
+    embedder, 200 queries through the reference's literal matcher (Q capped at 32 per call like
+    production.py's batch loop); extrapolated to one image with P = dpi proposals."""
+    from oracle import gln as og, macvgg as ovgg, crop as ocrop, match as omatch
+    from cvpce_amd import synthetic
+    cores = min(16, os.cpu_count() or 1)   # the GPU box's CPU share for one GPU; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    img = synthetic.shelf_image(0, image_size, image_size)
+    t = time.perf_counter()
+    res = og.gln_forward([img], det_sd, detections_per_img=dpi)[0]
+    t_det = time.perf_counter() - t
+    boxes = res['boxes'][res['scores'] > 0.5][:4]
+    if len(boxes) < 4:
+        boxes = torch.tensor([[10., 10., 300., 400.]] * 4)
+    t = time.perf_counter()
+    crops = ocrop.crop_boxes(img, boxes)
+    emb = ovgg.macvgg_forward(ocrop.scale_to_tanh(crops), enc_sd)
+    t_embed4 = time.perf_counter() - t
+    q = emb.repeat(8, 1)   # 32 queries
+    t = time.perf_counter()
+    omatch.nearest_neighbors_literal(gallery_emb, q, 1)
+    t_match32 = time.perf_counter() - t
+    per_image = t_det + t_embed4 / 4 * dpi + t_match32 / 32 * dpi
+    return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle (fp32 torch CPU restatement): 1 image {image_size}x{image_size} detector {t_det:.2f}s + '
+                      f'4 crops crop+embed {t_embed4:.2f}s + literal matcher 32 queries x {len(gallery_emb)} gallery '
+                      f'{t_match32:.2f}s, extrapolated to P={dpi} proposals/image'}
+
+
+def main():
+    args = parse()
+    from cvpce_amd import dist as cdist
+    rank, local_rank, world = cdist.init()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    from cvpce_amd import ops, production, synthetic
+
+    dpi = args.detections_per_img
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
+    enc = synthetic.synthetic_macvgg(seed=1)
+    det_sd = {k: v.clone() for k, v in det.state_dict().items()} if rank == 0 else None
+    enc_sd = {k: v.clone() for k, v in enc.state_dict().items()} if rank == 0 else None
+    det, enc = det.to(dev), enc.to(dev)
+
+    # gallery: embedded sharded (G/world rows per rank), assembled by ONE all_gather over RCCL/xGMI
+    gal_imgs = synthetic.gallery_images(args.gallery, seed=100)
+    t0 = time.perf_counter()
+    embed = lambda x: enc(x.to(dev))
+    s, e = cdist.shard_range(args.gallery, rank, world)
+    local = torch.cat([embed(gal_imgs[i:min(i + 128, e)]) for i in range(s, e, 128)]) if e > s else torch.empty(0, 1024, device=dev)
+    gallery = cdist.all_gather_rows(local, args.gallery, rank, world)
+    torch.cuda.synchronize()
+    t_gallery = time.perf_counter() - t0
+    del gal_imgs
+    mdt = torch.bfloat16 if args.match_dtype == 'bf16' else torch.float32
+    clf = production.Classifier.from_embedding(enc, gallery, [f'sku_{i:05d}' for i in range(args.gallery)],
+                                               device=dev, emb_device=dev, k=1, match_dtype=mdt)
+    pipe = production.BatchedPipeline(det, clf, 0.5)
+
+    images = [synthetic.shelf_image(1000 * rank + i, args.image_size, args.image_size).to(dev)
+              for i in range(args.images_per_gpu)]
+    torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = pipe.run(images)
+    torch.cuda.synchronize()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.run(images)
+    torch.cuda.synchronize()
+    cdist.barrier()
+    elapsed = cdist.max_over_ranks(time.perf_counter() - t0, dev)
+    proposals = float(sum(out['counts_host'])) / max(1, len(images))
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = ops.ConvProfile()
+        for _ in range(args.steps):
+            pipe.run(images)
+        summ = ops.PROFILE.summary()
+        ops.PROFILE = None
+        name, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
+        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
+                    'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
+                    'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4),
+                    'all_conv_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                                             'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}}
+
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
+
+    if rank == 0:
+        total_images = world * args.images_per_gpu * args.steps
+        line = {
+            'metric': 'shelf images/sec end-to-end (detect+embed+match)',
+            'value': round(total_images / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'full production path: {args.images_per_gpu} shelf images/GPU of 3x{args.image_size}x{args.image_size} '
+                                   f'(SKU-110K shape) -> GLN detect (800x800 internal, detections_per_img={dpi}, conf>0.5) -> RoI crop 256x256 '
+                                   f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
+                       'images_per_gpu': args.images_per_gpu, 'proposals_per_image': proposals, 'gallery': args.gallery,
+                       'match_dtype': args.match_dtype, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
+                       'parallelism': f'dp{world} (images sharded, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
+                       'gallery_build_s': round(t_gallery, 3)},
+        }
+        if roofline is not None:
+            line['roofline'] = roofline
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -67,6 +67,34 @@ class PackedConv:
         return ((h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1)
 
 
+class ConvProfile:
+    """Opt-in per-launch timing of the conv kernel with HIP events on the launch stream (bench.py roofline leg).
+
+    Kernel variant names mirror the dispatch in csrc/conv_igemm.hip (tile TC x TP, K-step BK)."""
+
+    def __init__(self):
+        self.records = []   # (variant, flops, start_event, end_event)
+
+    @staticmethod
+    def variant(pc):
+        tc = 128 if pc.cout > 64 else 64
+        bk = 64 if pc.cin_pad % 64 == 0 else 32
+        return f'conv_igemm_kernel<{tc},128,{bk},2,2>'
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+            d['launches'] += 1
+            d['flops'] += flops
+            d['ms'] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILE = None   # set to a ConvProfile() to record
+
+
 def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0, out=None):
     """x: NHWC bf16 (N,H,W,Cin_pad) -> NHWC (N,Ho,Wo,Cout) bf16 | f32."""
     _need_cuda(x, residual)
@@ -82,11 +110,19 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         hr, wr = residual.shape[1], residual.shape[2]
         if res_mode == 0:
             res_mode = 1 if (hr, wr) == (ho, wo) else 2
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
                                     pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),
                                     int(out_f32), int(in_up_shift), int(res_mode if residual is not None else 0),
                                     hr, wr, _stream())
     check(rc, 'cvpce_conv2d_nhwc_bf16')
+    if prof is not None:
+        e1.record()
+        # algorithmic FLOPs: real (unpadded) channels, 2 FLOP per MAC
+        prof.records.append((prof.variant(pc), 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, e0, e1))
     return out
 
 

@@ -56,6 +56,16 @@ class Classifier:
             self.embedding, self.annotations = self.load_index(load)
         self._refresh_gallery()
 
+    @classmethod
+    def from_embedding(cls, encoder, embedding, annotations, device=torch.device('cuda'), emb_device=torch.device('cuda'),
+                       batch_size=32, k=1, match_dtype=torch.bfloat16):
+        """Classifier over an index that already exists (e.g. embedded sharded across GPUs and all_gathered)."""
+        self = cls.__new__(cls)
+        self.batch_size, self.num_workers, self.device, self.emb_device = batch_size, 0, device, emb_device
+        self.k, self.encoder, self.match_dtype = k, encoder, match_dtype
+        self.set_index(embedding, annotations)
+        return self
+
     def _refresh_gallery(self):
         """Device-resident gallery operand of the distance GEMM (+ its row norms), built once."""
         g = ops.pad_features(self.embedding.to(device=self.device, dtype=self.match_dtype))
