@@ -1,0 +1,146 @@
+"""CPU-side checks of the drop-in boundary (no compute on a GPU):
+  * the C-ABI library loads and exports every symbol include/cvpce_amd.h declares;
+  * the Python surface mirrors the reference's names and state-dict keys;
+  * the product path refuses CPU tensors loudly (no CPU fallback, no oracle import)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'cvpce_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(cvpce_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cvpce_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 13
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/cvpce_amd.h but not exported'
+    assert sorted(_lib.SIGNATURES) == syms, 'ctypes signature table out of sync with the header'
+
+
+def test_workspace_queries_are_host_only():
+    from cvpce_amd._lib import lib
+    assert lib.cvpce_detect_workspace_bytes(8, 5, 1000) > 8 * 5000 * 79 * 8
+    assert lib.cvpce_match_workspace_bytes(1600, 3200, 1) >= 1600 * 25 * 8
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'cvpce_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """A copy of the package without libcvpce_hip.so must raise on import, not fall back."""
+    import shutil
+    dst = tmp_path / 'cvpce_amd'
+    shutil.copytree(os.path.join(ROOT, 'cvpce_amd'), dst, ignore=shutil.ignore_patterns('*.so', 'build', '__pycache__'))
+    r = subprocess.run([sys.executable, '-c', 'import cvpce_amd'], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and 'HipLibraryMissing' in r.stderr and 'no CPU fallback' in r.stderr
+
+
+def test_gln_state_dict_keys_match_reference_layout():
+    from cvpce_amd.models import proposals
+    m = proposals.gln(pretrained_backbone=False)
+    keys = set(m.state_dict())
+    must = [
+        'backbone.body.conv1.weight', 'backbone.body.bn1.running_var', 'backbone.body.layer1.0.downsample.0.weight',
+        'backbone.body.layer1.0.downsample.1.running_mean', 'backbone.body.layer3.5.conv3.weight',
+        'backbone.body.layer4.2.bn3.bias', 'backbone.fpn.inner_blocks.0.weight', 'backbone.fpn.inner_blocks.2.bias',
+        'backbone.fpn.layer_blocks.1.weight', 'backbone.fpn.extra_blocks.p6.weight', 'backbone.fpn.extra_blocks.p7.bias',
+        'backbone.gaussian_layer.lateral.weight', 'backbone.gaussian_layer.block1.conv.bias',
+        'backbone.gaussian_layer.block1.norm.running_mean', 'backbone.gaussian_layer.block2.norm.num_batches_tracked',
+        'backbone.gaussian_subnet.blocks.0.conv.weight', 'backbone.gaussian_subnet.blocks.4.conv.bias',
+        'head.classification_head.conv.0.weight', 'head.classification_head.conv.6.bias',
+        'head.classification_head.cls_logits.weight', 'head.regression_head.conv.4.weight',
+        'head.regression_head.bbox_reg.bias',
+    ]
+    for k in must:
+        assert k in keys, k
+    assert not any(k.startswith('backbone.body.fc') for k in keys)
+    assert not any('num_batches_tracked' in k for k in keys if k.startswith('backbone.body'))
+    sd = m.state_dict()
+    assert sd['backbone.body.conv1.weight'].shape == (64, 3, 7, 7)
+    assert sd['backbone.fpn.inner_blocks.0.weight'].shape == (256, 512, 1, 1)
+    assert sd['backbone.gaussian_layer.block1.conv.weight'].shape == (128, 256, 3, 3)
+    assert sd['backbone.gaussian_subnet.blocks.0.conv.weight'].shape == (32, 64, 3, 3)
+    assert sd['backbone.gaussian_subnet.blocks.4.conv.weight'].shape == (1, 16, 1, 1)
+    assert sd['head.classification_head.cls_logits.weight'].shape == (9, 256, 3, 3)
+    assert sd['head.regression_head.bbox_reg.weight'].shape == (36, 256, 3, 3)
+    n_params = sum(p.numel() for p in m.parameters())
+    assert 32.0e6 < n_params < 33.2e6, n_params          # GLN ~ 32.6 M parameters
+    # a DDP-saved checkpoint loads through trim_module_prefix (utils.py:276-278)
+    from cvpce_amd import utils
+    m2 = proposals.gln(pretrained_backbone=False)
+    m2.load_state_dict(utils.trim_module_prefix({'module.' + k: v for k, v in sd.items()}))
+    # torchvision FrozenBatchNorm2d drops a stray num_batches_tracked on load
+    sd2 = dict(sd); sd2['backbone.body.bn1.num_batches_tracked'] = torch.tensor(0)
+    m2.load_state_dict(sd2)
+
+
+def test_macvgg_state_dict_keys_match_reference_layout():
+    from cvpce_amd.models import classification as C
+    m = C.macvgg_embedder('vgg16', pretrained=False)
+    keys = sorted(m.state_dict())
+    want = [f'block1.{i}.{p}' for i in (0, 2, 5, 7, 10, 12, 14, 17, 19, 21) for p in ('bias', 'weight')] + \
+           [f'block2.{i}.{p}' for i in (24, 26, 28) for p in ('bias', 'weight')]
+    assert keys == sorted(want)
+    assert m.embedding_size == 1024 and C.MACVGG.embedding_size == 1024
+    assert sum(v.numel() for v in m.state_dict().values()) == 14714688      # VGG16 conv stack
+    bn = C.macvgg_embedder('vgg16_bn', pretrained=False)
+    assert 'block1.1.running_mean' in bn.state_dict() and 'block2.41.weight' in bn.state_dict()
+    with pytest.raises(NotImplementedError):
+        C.macvgg_embedder('resnet18', pretrained=False)
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from cvpce_amd import ops, production, datautils
+    from cvpce_amd.models import proposals, classification as C
+    with pytest.raises(RuntimeError, match='HIP'):
+        proposals.gln(pretrained_backbone=False)([torch.rand(3, 64, 64)])
+    with pytest.raises(RuntimeError, match='HIP'):
+        C.macvgg_embedder('vgg16', pretrained=False)(torch.rand(1, 3, 256, 256))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        C.nearest_neighbors(torch.rand(4, 8), torch.rand(2, 8))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        datautils.resize_for_classification(torch.rand(3, 10, 12))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.match_topk(torch.rand(2, 64), torch.rand(5, 64))
+    pg = production.ProposalGenerator(proposals.gln(pretrained_backbone=False), device=torch.device('cpu'))
+    assert pg.condfidence_threshold == 0.5       # (sic) production.py:12
+    with pytest.raises(RuntimeError):
+        pg.generate_proposals(torch.rand(3, 64, 64))
+
+
+def test_utils_and_reference_api_names():
+    from cvpce_amd import utils, datautils, production
+    from cvpce_amd.models import proposals, classification
+    t = torch.tensor([0.0, 0.25, 1.0])
+    assert torch.equal(utils.scale_to_tanh(t), torch.tensor([-1.0, -0.5, 1.0]))
+    assert torch.equal(utils.scale_from_tanh(utils.scale_to_tanh(t)), t)
+    assert datautils.CLASSIFICATION_IMAGE_SIZE == 256
+    for mod, names in ((proposals, ['gln', 'gln_backbone', 'GaussianLayerNetwork', 'GaussianLayer', 'GaussianSubnet',
+                                    'BackboneWithFPNAndGaussians']),
+                       (classification, ['MACVGG', 'macvgg_embedder', 'distance', 'nearest_neighbors']),
+                       (production, ['ProposalGenerator', 'Classifier', 'PlanogramEvaluator'])):
+        for n in names:
+            assert hasattr(mod, n), (mod.__name__, n)
+    d = classification.distance(torch.tensor([[1.0, 0.0]]), torch.tensor([[0.0, 1.0]]))
+    assert torch.allclose(d, torch.tensor([1.0]))

@@ -1,0 +1,74 @@
+"""The N>1 path rehearsed with world_size-2 (and 3) gloo processes on the CPU:
+image sharding is a partition, the sharded gallery build + one all_gather reproduces the single-rank
+gallery bit-for-bit, max-over-ranks timing reduction works."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_embed(x):
+    """Deterministic stand-in for the GPU embedder in this host-logic test: (b,3,8,8) -> (b,6)."""
+    return torch.stack([x.mean(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3)), x[:, 0].sum(dim=(1, 2)), x[:, 1].sum(dim=(1, 2)),
+                        x[:, 2].sum(dim=(1, 2)), x.amin(dim=(1, 2, 3))], dim=1)
+
+
+def _worker(rank, world, port, n_gallery, n_images, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from cvpce_amd import dist as cdist
+    r, _, w = cdist.init(backend='gloo')
+    assert (r, w) == (rank, world)
+    gal = torch.rand(n_gallery, 3, 8, 8, generator=torch.Generator().manual_seed(7))
+    full = cdist.build_gallery_sharded(_fake_embed, gal, rank, world)
+    mine = cdist.shard_images(n_images, rank, world)
+    t = cdist.max_over_ranks(float(rank + 1), torch.device('cpu'))
+    cdist.barrier()
+    q.put((rank, full, mine, t))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_gallery,n_images', [(2, 11, 16), (2, 4, 3), (3, 10, 64)])
+def test_sharded_gallery_and_image_partition(world, n_gallery, n_images):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_gallery, n_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gal = torch.rand(n_gallery, 3, 8, 8, generator=torch.Generator().manual_seed(7))
+    want = _fake_embed(gal)
+    seen = []
+    for rank, full, mine, t in results:
+        assert torch.equal(full, want), f'rank {rank}: gathered gallery differs from the single-rank gallery'
+        assert t == float(world)
+        seen += mine
+    assert sorted(seen) == list(range(n_images))        # every image on exactly one rank
+
+
+def test_shard_range_properties():
+    from cvpce_amd import dist as cdist
+    for n in (0, 1, 7, 64, 3200):
+        for world in (1, 2, 3, 8):
+            blocks = [cdist.shard_range(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [e - s for s, e in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert cdist.shard_range(64, 3, 8) == (24, 32)       # BASELINE config 5: 8 images per GPU
+    assert cdist.all_gather_rows(torch.ones(3, 2), 3, 0, 1).shape == (3, 2)

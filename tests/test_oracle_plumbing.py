@@ -1,0 +1,91 @@
+"""Oracle self-checks on the CPU: BASELINE config 1 plumbing (1x 640x640 random image, device cpu),
+torchvision-0.9 constants, edge cases of NMS / crop / matcher."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import crop as ocrop
+from oracle import gln as og
+from oracle import macvgg as ovgg
+from oracle import match as omatch
+
+
+@pytest.fixture(scope='module')
+def gln_sd():
+    from cvpce_amd import synthetic
+    return synthetic.synthetic_gln(seed=0, detections_per_img=50).state_dict()
+
+
+def test_config1_oracle_plumbing(gln_sd):
+    img = torch.rand(3, 640, 640, generator=torch.Generator().manual_seed(0))
+    res, inter = og.gln_forward([img], gln_sd, detections_per_img=50, return_intermediates=True)
+    r = res[0]
+    assert set(r) == {'boxes', 'scores', 'labels', 'gaussians'}
+    assert r['gaussians'].shape == (1, 400, 400)
+    assert r['boxes'].dtype == torch.float32 and r['labels'].dtype == torch.int64
+    assert 0 < len(r['boxes']) <= 50 and (r['scores'][:-1] >= r['scores'][1:]).all()
+    assert (r['boxes'][:, 2] <= 640).all() and (r['boxes'][:, :2] >= 0).all()
+    assert [tuple(f.shape[-2:]) for f in inter['features']] == [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)]
+    assert sum(a.shape[0] for a in inter['anchors']) == 120087
+    assert inter['image_sizes'] == [(800, 800)]
+
+
+def test_transform_sizes_and_anchor_constants():
+    assert og.resized_size(2048, 2048) == (800, 800) and og.resized_size(640, 640) == (800, 800)
+    assert og.resized_size(3000, 1000) == (1333, 444)                    # max-side cap
+    assert og.ANCHOR_SIZES == ((32, 40, 50), (64, 80, 101), (128, 161, 203), (256, 322, 406), (512, 645, 812))
+    b = og.base_anchors((32, 40, 50))
+    assert b.shape == (9, 4) and torch.equal(b[0], torch.tensor([-23., -11., 23., 11.]))
+    a = og.grid_anchors((800, 800), [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)])
+    assert torch.equal(a[3][9], a[3][0] + torch.tensor([61., 0., 61., 0.]))   # stride = 800 // 13 = 61
+    assert math.isclose(og.BBOX_XFORM_CLIP, math.log(62.5))
+    batch = og.batch_images([torch.ones(3, 800, 1066), torch.ones(3, 790, 1000)])
+    assert batch.shape == (2, 3, 800, 1088) and batch[1, :, 790:].abs().sum() == 0
+
+
+def test_nms_semantics():
+    boxes = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 5.1], [0., 0., 10., 5.0], [20., 20., 30., 30.], [0., 0., 10., 10.]])
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.6, 0.9])
+    keep = og.nms(boxes, scores, 0.5)
+    # IoU(0,1) = 0.51 > 0.5 suppressed; IoU(0,2) = 0.5 is NOT > 0.5 -> kept; duplicate 4 (tie -> lower index wins) suppressed
+    assert keep.tolist() == [0, 2, 3]
+    assert og.nms(torch.empty(0, 4), torch.empty(0), 0.5).numel() == 0
+    d = og.decode_single(torch.tensor([[0., 0., 100., 0.]]), torch.tensor([[0., 0., 16., 16.]]))
+    assert torch.allclose(d[0, 2] - d[0, 0], torch.tensor(1000.0), rtol=1e-5)   # exp(clip) * 16 = 1000
+
+
+def test_crop_semantics():
+    img = torch.rand(3, 50, 80, generator=torch.Generator().manual_seed(1))
+    full = ocrop.resize_for_classification(img)
+    assert full.shape == (3, 256, 256)
+    assert torch.allclose(full[:, 200:, :], torch.full((3, 56, 256), 0.5))        # bottom padding = 0.5 (80 > 50)
+    c = ocrop.crop_boxes(img, torch.tensor([[10.9, 5.9, 42.1, 37.9]]))            # truncation -> [5:37, 10:42] = 32x32
+    exp = F.interpolate(img[None, :, 5:37, 10:42], size=(256, 256), mode='bilinear', align_corners=False)[0]
+    assert torch.allclose(c[0], exp, atol=1e-6)
+    assert ocrop.crop_boxes(img, torch.empty(0, 4)).shape == (0, 3, 256, 256)
+    with pytest.raises(ValueError):
+        ocrop.crop_boxes(img, torch.tensor([[10.2, 5.0, 10.9, 30.0]]))           # zero width after .to(long)
+    big = torch.rand(3, 300, 300, generator=torch.Generator().manual_seed(2))    # identity when the crop is 256x256
+    assert torch.allclose(ocrop.crop_boxes(big, torch.tensor([[3., 4., 259., 260.]]))[0], big[:, 4:260, 3:259], atol=1e-6)
+
+
+def test_macvgg_oracle():
+    from cvpce_amd import synthetic
+    sd = synthetic.synthetic_macvgg(seed=1).state_dict()
+    x = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    e, d = ovgg.macvgg_forward(x, sd, return_descs=True)
+    assert e.shape == (2, 1024) and (e >= 0).all()
+    assert torch.allclose(e.norm(dim=1), torch.ones(2), atol=1e-5)
+    assert [p[0] for p in ovgg.feature_plan() if p[1] == 'conv'] == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+    z = ovgg.macvgg_forward(x, {k: torch.zeros_like(v) for k, v in sd.items()})
+    assert torch.isfinite(z).all() and (z == 0).all()                               # clamp(min=eps) path
+
+
+def test_matcher_oracle_edge_cases():
+    a = F.normalize(torch.rand(10, 16, generator=torch.Generator().manual_seed(4)), dim=1)
+    assert omatch.nearest_neighbors(a, a[[3, 7]], 1)[:, 0].tolist() == [3, 7]
+    assert omatch.nearest_neighbors_literal(a, a[[3, 7]], 3).shape == (2, 3)
+    ties = torch.ones(5, 4)
+    assert omatch.nearest_neighbors(ties, ties[:2], 3).tolist() == [[0, 1, 2], [0, 1, 2]]   # lowest index first
