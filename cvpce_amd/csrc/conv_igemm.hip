@@ -1,28 +1,43 @@
 // Implicit-GEMM convolution for gfx950 (CDNA4): NHWC bf16 activations, bf16
-// weights packed [Cout_pad][K_pad] with K = (kh*KW + kw)*Cin + ci, fp32
+// weights packed [Cout_pad][K_pad] (K order: see include/cvpce_amd.h), fp32
 // accumulation on v_mfma_f32_32x32x16_bf16, fused bias / residual(+nearest
-// upsample) / ReLU epilogue, bf16 or fp32 NHWC output.
+// upsample) / ReLU / 2x2-max-pool epilogue, bf16 or fp32 NHWC output.
 //
 // GEMM view (transposed so that the accumulator's register axis runs along
 // Cout -> each lane owns 4 consecutive output channels of ONE pixel and the
 // NHWC store is 8 B/lane, 64 B contiguous per pixel):
 //     D[cout][pixel] = sum_k Wgt[cout][k] * Im2col[pixel][k]
 // The im2col matrix is never materialised: every 16-byte K-chunk of a pixel
-// row is gathered straight from the NHWC tensor (one tap, 8 channels), with
-// zero fill for the padding halo, staged through registers into an
-// XOR-swizzled LDS tile (conflict-free ds_read_b128 fragments), double
-// buffered with the global loads of K-step t+1 in flight under the MFMAs of
-// step t.
+// row is gathered straight from the NHWC tensor (one tap, 8 channels) into an
+// XOR-swizzled LDS tile (conflict-free ds_read_b128 fragments).
 //
-// Covers every convolution of the hot path:
-//   ResNet-50 7x7 s2 / 1x1 / 3x3 s1,s2; FPN 1x1, 3x3, 3x3 s2; RetinaNet head
-//   3x3; Gaussian branch 1x1/3x3 (incl. reading a nearest-2x-upsampled input
-//   without materialising it); VGG16 3x3.
+// Two kernels share the tiling, the fragment reads and the epilogue:
+//   conv_dma_kernel    the workhorse (Cin % 64 == 0, big M): 8 waves, 256x256
+//                      (or 4 waves, 128/64 x 256) output tile, K-step 64, operands
+//                      staged by LDS-DMA (`global_load_lds_dwordx4`, no VGPR round
+//                      trip, no ds_write); the XOR swizzle is applied to the per-lane
+//                      SOURCE address (the DMA writes LDS lane-linearly) and padding
+//                      halo / ragged rows read a 16-byte zero page.  Double buffered:
+//                      the DMA of K-step t+1 is in flight under the MFMAs of step t.
+//   conv_igemm_kernel  the generic fallback (any Cin % 8 == 0, small M, thin
+//                      channels): 4 waves, 128/64 x 128 tile, register-staged.
+//
+// fuse_pool2: the M axis enumerates output pixels in 2x2-quad order so the four
+// pixels of a pooling window sit in four adjacent lanes; the epilogue takes the
+// max with two cross-lane shuffles and stores only the pooled tensor
+// (VGG16 conv1_2 / conv2_2 / conv3_3 / conv4_3 + MaxPool2d(2,2)).
+//
+// Covers every convolution of the hot path.
 // Reference semantics: torch.nn.Conv2d as used at
 //   /root/reference/cvpce/models/proposals.py:54,68,84 and torchvision 0.9
 //   resnet/vgg/fpn/retinanet.
 #include "common.h"
 #include "../../include/cvpce_amd.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __attribute__((aligned(16))) unsigned int cvpce_zero_page[4] = {0u, 0u, 0u, 0u};
 
 struct ConvArgs {
     const bf16_t* in;
@@ -37,9 +52,432 @@ struct ConvArgs {
     int relu, out_f32;
     int in_up_shift;
     int res_mode, Hr, Wr;
+    int pool;
     int tiles_p, tiles_c;
 };
 
+// M index -> (image, oy, ox).  Row-major, or 2x2-quad order when the pool is fused.
+__device__ __forceinline__ void decode_m(const ConvArgs& a, int m, int& img, int& oy, int& ox) {
+    if (a.pool) {
+        const int q = m >> 2, sub = m & 3;
+        const int qw = a.Wo >> 1, qhw = (a.Ho >> 1) * qw;
+        img = q / qhw;
+        const int rem = q - img * qhw;
+        const int qy = rem / qw, qx = rem - qy * qw;
+        oy = 2 * qy + (sub >> 1);
+        ox = 2 * qx + (sub & 1);
+    } else {
+        const int hw = a.Ho * a.Wo;
+        img = m / hw;
+        const int rem = m - img * hw;
+        oy = rem / a.Wo;
+        ox = rem - oy * a.Wo;
+    }
+}
+
+// Epilogue shared by both kernels: lane owns pixel (lane&31) of each 32-wide
+// pixel tile and channels 8g + 4h + {0..3} of each 32-channel tile.
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int c_base, int p_base, int lane) {
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int m = p_base + nt * 32 + lr;
+        const bool m_ok = m < a.M;
+        size_t res_pix = 0;
+        if (a.res_mode == 1) {
+            res_pix = (size_t)m;
+        } else if (a.res_mode == 2 && m_ok) {
+            int img, oy, ox;
+            decode_m(a, m, img, oy, ox);
+            const int ry = (oy * a.Hr) / a.Ho, rx = (ox * a.Wr) / a.Wo;
+            res_pix = (size_t)(img * a.Hr + ry) * a.Wr + rx;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = c_base + mt * 32 + 8 * g + 4 * lh;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][4 * g + j];
+                if (a.out_f32) {
+                    if (!m_ok || co >= a.Cout) continue;
+                    float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (co + j < a.Cout) {
+                            float x = v[j];
+                            if (a.bias) x += a.bias[co + j];
+                            if (a.res_mode) x += bf16_to_f32(a.res[res_pix * a.Cout + co + j]);
+                            if (a.relu == 1) x = fmaxf(x, 0.f);
+                            else if (a.relu == 2) x = tanhf(x);
+                            o[co + j] = x;
+                        }
+                    }
+                } else if (a.pool) {
+                    // all 4 lanes of a quad share m_ok / co: shuffles stay convergent
+                    if (a.bias && co < a.Cout) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += b[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = v[j];
+                        x = fmaxf(x, __shfl_xor(x, 1));
+                        x = fmaxf(x, __shfl_xor(x, 2));
+                        if (a.relu == 1) x = fmaxf(x, 0.f);
+                        v[j] = x;
+                    }
+                    if (m_ok && co < a.Cout && (lane & 3) == 0) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)(m >> 2) * a.Cout + co) = o;
+                    }
+                } else {
+                    if (!m_ok || co >= a.Cout) continue;
+                    // Cout % 4 == 0 is required for bf16 outputs (checked on the host)
+                    if (a.bias) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += b[j];
+                    }
+                    if (a.res_mode) {
+                        const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + res_pix * a.Cout + co);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r[j]);
+                    }
+                    if (a.relu == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
+                }
+            }
+        }
+    }
+}
+
+// One K-step (BK) of MFMAs from a swizzled [rows][BK] LDS image pair.
+template <int MT, int NT, int BK>
+__device__ __forceinline__ void mfma_kstep(const bf16_t* Wb, const bf16_t* Pb, int wrow0, int prow0, int lane,
+                                           f32x16 (&acc)[MT][NT]) {
+    constexpr int CPR = BK / 8, RPB = 256 / (BK * 2);
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+        const int chunk = kk * 2 + lh;
+        bf16x8 af[MT], bfr[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wrow0 + mt * 32 + lr;
+            af[mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row / RPB) & (CPR - 1))) * 8));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int row = prow0 + nt * 32 + lr;
+            bfr[nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row / RPB) & (CPR - 1))) * 8));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+    }
+}
+
+// ===========================================================================
+// LDS-DMA kernel
+// ===========================================================================
+template <int TC, int TP, int WC, int WP, int MINW>
+__global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma_kernel(ConvArgs a) {
+    constexpr int BK = 64;
+    constexpr int NW = WC * WP;
+    constexpr int WJ = TC / (8 * NW);      // weight DMA instructions per wave per K-step (8 rows each)
+    constexpr int PJ = TP / (8 * NW);      // pixel  DMA instructions per wave per K-step
+    constexpr int MT = TC / WC / 32;
+    constexpr int NT = TP / WP / 32;
+    static_assert(WJ >= 1 && PJ >= 1 && (8 * NW) % 16 == 0, "tile/wave geometry");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);          // [2][TC][BK]
+    bf16_t* Ps = Ws + 2 * TC * BK;                         // [2][TP][BK]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid / WP, wp = wid % WP;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = swz % a.tiles_c, tile_p = swz / a.tiles_c;
+
+    // DMA geometry: instruction j of wave w fills tile rows j*8*NW + w*8 .. +7 (1 KiB, lane-linear:
+    // row = lane>>3, physical chunk = lane&7).  The swizzle f(row) = (row>>1)&7 does not depend on j
+    // (8*NW is a multiple of 16), so each lane stages ONE logical K-chunk for all its rows.
+    const int lrow = wid * 8 + (lane >> 3);
+    const int lchunk = (lane & 7) ^ ((lrow >> 1) & 7);
+
+    const int Hl = a.H << a.in_up_shift, Wl = a.W << a.in_up_shift;
+    int pbase[PJ], piy[PJ], pix[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int m = tile_p * TP + j * 8 * NW + lrow;
+        if (m < a.M) {
+            int img, oy, ox;
+            decode_m(a, m, img, oy, ox);
+            piy[j] = oy * a.stride - a.pad;
+            pix[j] = ox * a.stride - a.pad;
+            pbase[j] = img * a.H * a.W;
+        } else {
+            piy[j] = -(1 << 28);
+            pix[j] = 0;
+            pbase[j] = 0;
+        }
+    }
+    int ci = lchunk * 8, kh = 0, kw = 0;      // (channel, tap) of this lane's K-chunk; Cin % 64 == 0 here
+    const bf16_t* wsrc = a.wgt + (size_t)(tile_c * TC + lrow) * a.K_pad + lchunk * 8;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(cvpce_zero_page);
+
+    // A K-step's DMA is split in two: CVPCE_DMA_ADDR computes the per-lane source pointers of the NEXT
+    // K-step (VALU only), CVPCE_DMA_ISSUE(i) fires piece i.  The pieces are spread between the four
+    // MFMA groups of the CURRENT K-step, so DMA issue slots hide under matrix-pipe time instead of
+    // forming an MFMA-free bubble at the head of every K-step (both waves of a SIMD run in lockstep
+    // after the barrier, so the partner wave cannot fill that bubble).
+    constexpr int NP = WJ + PJ;              // DMA pieces per wave per K-step
+    constexpr int NPK = (NP + 3) / 4;        // pieces issued per MFMA group
+    const bf16_t* dsrc[NP];
+#define CVPCE_DMA_ADDR(KT)                                                                                     \
+    {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j)                                                         \
+            dsrc[j] = wsrc + (size_t)j * 8 * NW * a.K_pad + (KT) * BK;                                         \
+        const bool tap_ok = ci < a.Cin;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                                                       \
+            const int iy = piy[j] + kh, ix = pix[j] + kw;                                                      \
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;              \
+            const size_t off =                                                                                 \
+                (size_t)(pbase[j] + (iy >> a.in_up_shift) * a.W + (ix >> a.in_up_shift)) * a.Cin + ci;         \
+            dsrc[WJ + j] = ok ? a.in + off : zero;                                                             \
+        }                                                                                                      \
+        /* K order for Cin % 64 == 0: (64-channel chunk, kh, kw, channel) -- the 9 taps of one chunk are */    \
+        /* consecutive K-steps, so their overlapping pixel reads hit the XCD's L2 instead of the fabric   */    \
+        if (++kw == a.KW) {                                                                                    \
+            kw = 0;                                                                                            \
+            if (++kh == a.KH) { kh = 0; ci += BK; }                                                            \
+        }                                                                                                      \
+    }
+#define CVPCE_DMA_ISSUE(I, BUF)                                                                                \
+    {                                                                                                          \
+        if ((I) < WJ)                                                                                          \
+            __builtin_amdgcn_global_load_lds((gbl_void*)dsrc[(I)],                                             \
+                (lds_void*)(Ws + (BUF) * TC * BK + ((I) * 8 * NW + wid * 8) * BK), 16, 0, 0);                  \
+        else                                                                                                   \
+            __builtin_amdgcn_global_load_lds((gbl_void*)dsrc[(I)],                                             \
+                (lds_void*)(Ps + (BUF) * TP * BK + (((I) - WJ) * 8 * NW + wid * 8) * BK), 16, 0, 0);           \
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = a.K_pad / BK;
+    CVPCE_DMA_ADDR(0)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) CVPCE_DMA_ISSUE(i, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) CVPCE_DMA_ADDR(kt + 1)
+        const bf16_t* Wb = Ws + cur * TC * BK;
+        const bf16_t* Pb = Ps + cur * TP * BK;
+        // fragments are double buffered in registers: the ds_reads of group kk+1 are in flight under the
+        // MFMAs of group kk, so only the first group of a K-step exposes LDS latency
+        bf16x8 af[2][MT], bfr[2][NT];
+#define CVPCE_LOAD_FRAGS(KK, SLOT)                                                                             \
+        {                                                                                                      \
+            const int chunk = (KK) * 2 + lh;                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
+                const int row = wc * (TC / WC) + mt * 32 + lr;                                                 \
+                af[SLOT][mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row >> 1) & 7)) * 8)); \
+            }                                                                                                  \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                \
+                const int row = wp * (TP / WP) + nt * 32 + lr;                                                 \
+                bfr[SLOT][nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row >> 1) & 7)) * 8)); \
+            }                                                                                                  \
+        }
+        CVPCE_LOAD_FRAGS(0, 0)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) CVPCE_LOAD_FRAGS(kk + 1, (kk + 1) & 1)
+            if (more) {
+#pragma unroll
+                for (int i = kk * NPK; i < (kk + 1) * NPK && i < NP; ++i) CVPCE_DMA_ISSUE(i, cur ^ 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ds_reads / DMA issue AHEAD of this MFMA group
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][mt], bfr[kk & 1][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef CVPCE_LOAD_FRAGS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef CVPCE_DMA_ADDR
+#undef CVPCE_DMA_ISSUE
+    conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+}
+
+// ===========================================================================
+// LDS-DMA kernel, 4-stage ring: K-step 32, three K-steps of DMA in flight
+// ===========================================================================
+// Issued -> landed latency of an LDS-DMA piece under load is ~1 us (about one 64-deep K-step of
+// MFMA time), so a 2-buffer scheme exposes it every step.  Here the ring holds four 32-deep
+// K-steps (4 x 32 KiB at 256x256): stage t+3 is issued while stage t computes, the wave waits with
+// a COUNTED vmcnt (never 0 in steady state) and a raw s_barrier (a __syncthreads() would drain
+// vmcnt to 0).  K order: (64-channel chunk, kh, kw, 32-channel half, channel).
+template <int TC, int TP, int WC, int WP, int MINW>
+__global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs a) {
+    constexpr int BK = 32, NS = 4;
+    constexpr int NW = WC * WP;
+    constexpr int WJ = TC / (16 * NW);     // weight DMA pieces per wave per K-step (16 rows of 64 B each)
+    constexpr int PJ = TP / (16 * NW);
+    constexpr int NP = WJ + PJ;
+    constexpr int MT = TC / WC / 32;
+    constexpr int NT = TP / WP / 32;
+    static_assert(WJ >= 1 && PJ >= 1, "tile/wave geometry");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);          // [NS][TC][BK]
+    bf16_t* Ps = Ws + NS * TC * BK;                        // [NS][TP][BK]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid / WP, wp = wid % WP;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = swz % a.tiles_c, tile_p = swz / a.tiles_c;
+
+    // piece j of wave w fills rows j*16*NW + w*16 .. +15 (row = lane>>2, physical chunk = lane&3);
+    // swizzle f(row) = (row>>2)&3 = (lane>>4)&3 is the same for every piece of a lane
+    const int lrow = wid * 16 + (lane >> 2);
+    const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+
+    const int Hl = a.H << a.in_up_shift, Wl = a.W << a.in_up_shift;
+    int pbase[PJ], piy[PJ], pix[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int m = tile_p * TP + j * 16 * NW + lrow;
+        if (m < a.M) {
+            int img, oy, ox;
+            decode_m(a, m, img, oy, ox);
+            piy[j] = oy * a.stride - a.pad;
+            pix[j] = ox * a.stride - a.pad;
+            pbase[j] = img * a.H * a.W;
+        } else {
+            piy[j] = -(1 << 28);
+            pix[j] = 0;
+            pbase[j] = 0;
+        }
+    }
+    int ci = lchunk * 8, kh = 0, kw = 0, half = 0;     // channel = ci + 32*half
+    const bf16_t* wsrc = a.wgt + (size_t)(tile_c * TC + lrow) * a.K_pad + lchunk * 8;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(cvpce_zero_page);
+
+#define CVPCE_DMA4_STAGE(KT, BUF)                                                                              \
+    {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j) {                                                       \
+            const bf16_t* src = wsrc + (size_t)j * 16 * NW * a.K_pad + (KT) * BK;                              \
+            __builtin_amdgcn_global_load_lds((gbl_void*)src,                                                   \
+                (lds_void*)(Ws + (BUF) * TC * BK + (j * 16 * NW + wid * 16) * BK), 16, 0, 0);                  \
+        }                                                                                                      \
+        const int ch = ci + 32 * half;                                                                         \
+        const bool tap_ok = ch < a.Cin;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                                                       \
+            const int iy = piy[j] + kh, ix = pix[j] + kw;                                                      \
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;              \
+            const size_t off =                                                                                 \
+                (size_t)(pbase[j] + (iy >> a.in_up_shift) * a.W + (ix >> a.in_up_shift)) * a.Cin + ch;         \
+            const bf16_t* src = ok ? a.in + off : zero;                                                        \
+            __builtin_amdgcn_global_load_lds((gbl_void*)src,                                                   \
+                (lds_void*)(Ps + (BUF) * TP * BK + (j * 16 * NW + wid * 16) * BK), 16, 0, 0);                  \
+        }                                                                                                      \
+        half ^= 1;                                                                                             \
+        if (half == 0) {                                                                                       \
+            if (++kw == a.KW) {                                                                                \
+                kw = 0;                                                                                        \
+                if (++kh == a.KH) { kh = 0; ci += 64; }                                                        \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = a.K_pad / BK;
+    // prologue: three stages in flight
+    CVPCE_DMA4_STAGE(0, 0)
+    if (nk > 1) CVPCE_DMA4_STAGE(1, 1)
+    if (nk > 2) CVPCE_DMA4_STAGE(2, 2)
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire stage kt: stages kt+1, kt+2 may stay in flight (NP pieces each)
+        const int ahead = nk - 1 - kt;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // stage kt landed for every wave; everyone is done with stage kt-1's buffer
+        if (kt + 3 < nk) CVPCE_DMA4_STAGE(kt + 3, (kt + 3) & 3)
+        const bf16_t* Wb = Ws + (kt & 3) * TC * BK;
+        const bf16_t* Pb = Ps + (kt & 3) * TP * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 2 + lh;
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wc * (TC / WC) + mt * 32 + lr;
+                af[mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int row = wp * (TP / WP) + nt * 32 + lr;
+                bfr[nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+#undef CVPCE_DMA4_STAGE
+    conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+}
+
+// ===========================================================================
+// generic register-staged kernel
+// ===========================================================================
 template <int TC, int TP, int BK, int WC, int WP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int CPR = BK / 8;             // 16-byte chunks per tile row
@@ -65,17 +503,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int r0 = tid / CPR;
 
     const int Hl = a.H << a.in_up_shift, Wl = a.W << a.in_up_shift;
-    const int HoWo = a.Ho * a.Wo;
 
     int pbase[PPASS], piy[PPASS], pix[PPASS];
 #pragma unroll
     for (int i = 0; i < PPASS; ++i) {
-        int m = tile_p * TP + r0 + i * RPP;
+        const int m = tile_p * TP + r0 + i * RPP;
         if (m < a.M) {
-            int img = m / HoWo;
-            int rem = m - img * HoWo;
-            int oy = rem / a.Wo;
-            int ox = rem - oy * a.Wo;
+            int img, oy, ox;
+            decode_m(a, m, img, oy, ox);
             piy[i] = oy * a.stride - a.pad;
             pix[i] = ox * a.stride - a.pad;
             pbase[i] = img * a.H * a.W;
@@ -99,20 +534,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < WPASS; ++i) wreg[i] =                                            \
             *reinterpret_cast<const u32x4*>(wrow + (size_t)i * RPP * a.K_pad + (KT) * BK);                     \
-        const bool tap_ok = kh < a.KH;                                                                         \
+        const bool tap_ok = (BK == 64) ? (ci < a.Cin) : (kh < a.KH);                                           \
         _Pragma("unroll") for (int i = 0; i < PPASS; ++i) {                                                    \
             const int iy = piy[i] + kh, ix = pix[i] + kw;                                                      \
             const bool ok = tap_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;              \
             const size_t off =                                                                                 \
                 (size_t)(pbase[i] + (iy >> a.in_up_shift) * a.W + (ix >> a.in_up_shift)) * a.Cin + ci;         \
-            u32x4 v = {0u, 0u, 0u, 0u};                                                                          \
+            u32x4 v = {0u, 0u, 0u, 0u};                                                                        \
             if (ok) v = *reinterpret_cast<const u32x4*>(a.in + off);                                           \
             preg[i] = v;                                                                                       \
         }                                                                                                      \
-        ci += BK;                                                                                              \
-        while (ci >= a.Cin) {                                                                                  \
-            ci -= a.Cin;                                                                                       \
-            if (++kw == a.KW) { kw = 0; ++kh; }                                                                \
+        if (BK == 64) { /* chunk-major K order (Cin % 64 == 0), see conv_dma_kernel */                         \
+            if (++kw == a.KW) {                                                                                \
+                kw = 0;                                                                                        \
+                if (++kh == a.KH) { kh = 0; ci += BK; }                                                        \
+            }                                                                                                  \
+        } else {        /* tap-major K order: (kh, kw, channel) */                                             \
+            ci += BK;                                                                                          \
+            while (ci >= a.Cin) {                                                                              \
+                ci -= a.Cin;                                                                                   \
+                if (++kw == a.KW) { kw = 0; ++kh; }                                                            \
+            }                                                                                                  \
         }                                                                                                      \
     }
 #define CVPCE_STORE_TILE(BUF)                                                                                  \
@@ -142,99 +584,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     CVPCE_STORE_TILE(0)
     __syncthreads();
     int cur = 0;
-    const int lr = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) CVPCE_LOAD_TILE(kt + 1)
-        const bf16_t* Wb = Ws + cur * TC * BK;
-        const bf16_t* Pb = Ps + cur * TP * BK;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int chunk = kk * 2 + lh;
-            bf16x8 af[MT], bfr[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                int row = wc * (TC / WC) + mt * 32 + lr;
-                af[mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row / RPB) & (CPR - 1))) * 8));
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                int row = wp * (TP / WP) + nt * 32 + lr;
-                bfr[nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row / RPB) & (CPR - 1))) * 8));
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
-        }
+        mfma_kstep<MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc);
         if (more) CVPCE_STORE_TILE(cur ^ 1)
         __syncthreads();
         cur ^= 1;
     }
-
-    // ---- epilogue: lane owns pixel (lane&31) of each 32-wide pixel tile and
-    // channels 8g + 4h + {0..3} of each 32-channel tile.
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int m = tile_p * TP + wp * (TP / WP) + nt * 32 + lr;
-        if (m >= a.M) continue;
-        size_t res_pix = 0;
-        if (a.res_mode == 1) {
-            res_pix = (size_t)m;
-        } else if (a.res_mode == 2) {
-            int img = m / HoWo;
-            int rem = m - img * HoWo;
-            int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            int ry = (oy * a.Hr) / a.Ho, rx = (ox * a.Wr) / a.Wo;
-            res_pix = (size_t)(img * a.Hr + ry) * a.Wr + rx;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = tile_c * TC + wc * (TC / WC) + mt * 32 + 8 * g + 4 * lh;
-                if (co >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][4 * g + j];
-                if (a.out_f32) {
-                    float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (co + j < a.Cout) {
-                            float x = v[j];
-                            if (a.bias) x += a.bias[co + j];
-                            if (a.res_mode) x += bf16_to_f32(a.res[res_pix * a.Cout + co + j]);
-                            if (a.relu == 1) x = fmaxf(x, 0.f);
-                            else if (a.relu == 2) x = tanhf(x);
-                            o[co + j] = x;
-                        }
-                    }
-                } else {
-                    // Cout % 4 == 0 is required for bf16 outputs (checked on the host)
-                    if (a.bias) {
-                        f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += b[j];
-                    }
-                    if (a.res_mode) {
-                        bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + res_pix * a.Cout + co);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r[j]);
-                    }
-                    if (a.relu == 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
-                }
-            }
-        }
-    }
+#undef CVPCE_LOAD_TILE
+#undef CVPCE_STORE_TILE
+    conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
 template <int TC, int TP, int BK, int WC, int WP>
@@ -248,14 +608,51 @@ static int launch_conv(const ConvArgs& a0, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
+template <int TC, int TP, int WC, int WP, int MINW>
+static int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_p = (a.M + TP - 1) / TP;
+    a.tiles_c = (a.Cout + TC - 1) / TC;
+    const size_t smem = (size_t)2 * (TC + TP) * 64 * sizeof(bf16_t);
+    static bool attr_set = false;     // one flag per template instance
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_dma_kernel<TC, TP, WC, WP, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_p * a.tiles_c);
+    hipLaunchKernelGGL((conv_dma_kernel<TC, TP, WC, WP, MINW>), grid, dim3(WC * WP * 64), smem, stream, a);
+    return cvpce_check_launch();
+}
+
+template <int TC, int TP, int WC, int WP, int MINW>
+static int launch_conv_dma4(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_p = (a.M + TP - 1) / TP;
+    a.tiles_c = (a.Cout + TC - 1) / TC;
+    const size_t smem = (size_t)4 * (TC + TP) * 32 * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_dma4_kernel<TC, TP, WC, WP, MINW>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_p * a.tiles_c);
+    hipLaunchKernelGGL((conv_dma4_kernel<TC, TP, WC, WP, MINW>), grid, dim3(WC * WP * 64), smem, stream, a);
+    return cvpce_check_launch();
+}
+
 extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res,
                                       void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                       int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
                                       int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
-                                      void* stream) {
+                                      int fuse_pool2, int force_generic, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
-    if (Cin % 8 != 0 || K_pad % 64 != 0 || Cout_pad % 128 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
+    if (Cin % 8 != 0 || K_pad % 32 != 0 || (Cin % 64 == 0 && K_pad % 64 != 0) || Cout_pad % 256 != 0 || Cout_pad < Cout)
+        return CVPCE_ERR_ARG;
     if (K_pad < KH * KW * Cin) return CVPCE_ERR_ARG;
     if (!out_f32 && (Cout % 4 != 0)) return CVPCE_ERR_ARG;
     if (!out_f32 && act == 2) return CVPCE_ERR_ARG;
@@ -265,13 +662,25 @@ extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const flo
     if (Ho != (Hl + 2 * pad - KH) / stride + 1 || Wo != (Wl + 2 * pad - KW) / stride + 1) return CVPCE_ERR_ARG;
     if ((long long)N * H * W * Cin >= (1LL << 31) || (long long)N * Ho * Wo >= (1LL << 31) / 4) return CVPCE_ERR_ARG;
     if (res_mode == 1 && (Hr != Ho || Wr != Wo)) return CVPCE_ERR_ARG;
+    if (fuse_pool2 && (out_f32 || res_mode || (Ho & 1) || (Wo & 1))) return CVPCE_ERR_ARG;
     ConvArgs a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.res = (const bf16_t*)res; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.Ho = Ho; a.Wo = Wo; a.K_pad = K_pad; a.M = N * Ho * Wo; a.relu = act; a.out_f32 = out_f32;
-    a.in_up_shift = in_up_shift; a.res_mode = res_mode; a.Hr = Hr; a.Wr = Wr; a.tiles_p = a.tiles_c = 0;
+    a.in_up_shift = in_up_shift; a.res_mode = res_mode; a.Hr = Hr; a.Wr = Wr; a.pool = fuse_pool2 ? 1 : 0;
+    a.tiles_p = a.tiles_c = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool bk64 = (Cin % 64 == 0);
+    // LDS-DMA workhorse: K-step 64 within one tap, and enough pixel tiles to fill 256 CUs.
+    //   Cout >= 192: 8 waves, 256x256 tile, 128 KiB LDS, 1 workgroup / CU (2 waves / SIMD)
+    //   Cout <= 128: 4 waves, 128x128 or 64x128 tile, 64 / 48 KiB LDS, 2 workgroups / CU
+    const long long tiles256 = ((long long)a.M + 255) / 256;
+    if (bk64 && force_generic != 1) {
+        if (Cout >= 192 && tiles256 * ((Cout + 255) / 256) >= 128)
+            return (force_generic == 2) ? launch_conv_dma<256, 256, 2, 4, 2>(a, s) : launch_conv_dma4<256, 256, 2, 4, 2>(a, s);
+        if (Cout > 64 && Cout <= 128 && tiles256 >= 128) return launch_conv_dma<128, 128, 2, 2, 2>(a, s);
+        if (Cout > 32 && Cout <= 64 && tiles256 >= 128) return launch_conv_dma<64, 128, 2, 2, 2>(a, s);
+    }
     if (Cout > 64) {
         return bk64 ? launch_conv<128, 128, 64, 2, 2>(a, s) : launch_conv<128, 128, 32, 2, 2>(a, s);
     } else {

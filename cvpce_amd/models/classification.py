@@ -23,6 +23,7 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 TANH_MEAN = tuple(m * 2 - 1 for m in IMAGENET_MEAN)
 TANH_STD = tuple(s * 2 for s in IMAGENET_STD)
 INPUT_SIZE = 256
+USE_FUSED_STEM = True   # A/B switch (tests compare the fused stem against the unfused conv kernels)
 MAX_EMBED_BATCH = 256  # crops per kernel schedule pass (keeps every NHWC tensor < 2^31 elements)
 
 
@@ -50,7 +51,10 @@ class MACVGGEngine:
             if isinstance(m, str):
                 self.plan.append(('desc', None))
             elif isinstance(m, nn.MaxPool2d):
-                self.plan.append(('pool', None))
+                if self.plan and self.plan[-1][0] == 'conv':
+                    self.plan[-1] = ('conv_pool', self.plan[-1][1])   # MaxPool2d(2,2) fused into the conv epilogue
+                else:
+                    self.plan.append(('pool', None))
             elif isinstance(m, nn.Conv2d):
                 scale = shift = None
                 if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
@@ -59,6 +63,22 @@ class MACVGGEngine:
                     shift = bn.bias - bn.running_mean * scale
                 self.plan.append(('conv', ops.PackedConv(m.weight, m.bias, 1, 1, scale=scale, shift=shift, device=device)))
             i += 1
+        # conv1_1 + conv1_2 + pool1 fused into one persistent kernel when the plan starts with exactly that
+        self.stem = None
+        if (USE_FUSED_STEM and len(self.plan) >= 2 and self.plan[0][0] == 'conv' and self.plan[1][0] == 'conv_pool'
+                and self.plan[0][1].cin == 3 and self.plan[0][1].cout == 64 and self.plan[1][1].cout == 64):
+            packed = []
+            for i, m in enumerate(mods):
+                if isinstance(m, nn.Conv2d) and len(packed) < 4:
+                    w, b = m.weight.detach().float().cpu(), m.bias.detach().float().cpu()
+                    if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):   # eval-mode BN folded in
+                        bn = mods[i + 1]
+                        sc = (bn.weight * (bn.running_var + bn.eps).rsqrt()).detach().float().cpu()
+                        w = w * sc[:, None, None, None]
+                        b = b * sc + (bn.bias.detach().float().cpu() - bn.running_mean.detach().float().cpu() * sc)
+                    packed += [w, b]
+            self.stem = ops.PackedStem(*packed, device=device)
+            self.plan = self.plan[2:]
         self.device = device
         self.embedding_size = model.embedding_size
 
@@ -69,9 +89,13 @@ class MACVGGEngine:
             xb = x[s:s + MAX_EMBED_BATCH]
             desc = torch.empty((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)
             off = 0
+            if self.stem is not None:
+                xb = ops.vgg_stem(xb, self.stem)
             for kind, pc in self.plan:
                 if kind == 'conv':
                     xb = ops.conv2d(xb, pc, act=1)
+                elif kind == 'conv_pool':
+                    xb = ops.conv2d(xb, pc, act=1, pool=True)
                 elif kind == 'pool':
                     xb = ops.maxpool2d(xb, 2, 2)
                 else:

@@ -34,7 +34,7 @@ def _need_cuda(*ts):
 # weights
 # ---------------------------------------------------------------------------
 class PackedConv:
-    """bf16 [Cout_pad][K_pad] weight + fp32 bias, K = (kh*KW + kw)*Cin_pad + ci."""
+    """bf16 [Cout_pad][K_pad] weight + fp32 bias in the K order of include/cvpce_amd.h."""
 
     def __init__(self, weight, bias=None, stride=1, pad=0, scale=None, shift=None, device='cuda'):
         """weight (Cout,Cin,KH,KW) f32; optional per-Cout affine folded in:
@@ -53,10 +53,14 @@ class PackedConv:
         self.cin_pad = (cin + 7) // 8 * 8
         self.cout, self.kh, self.kw, self.stride, self.pad = cout, kh, kw, stride, pad
         k = kh * kw * self.cin_pad
-        self.k_pad = (k + 63) // 64 * 64
-        self.cout_pad = (cout + 127) // 128 * 128
+        kq = 64 if self.cin_pad % 64 == 0 else 32   # K-step of the kernel that will run this layer
+        self.k_pad = (k + kq - 1) // kq * kq
+        self.cout_pad = (cout + 255) // 256 * 256
         wp = torch.zeros(self.cout_pad, kh, kw, self.cin_pad, dtype=torch.float32)
         wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+        if self.cin_pad % 64 == 0:
+            # chunk-major K: (64-channel chunk, kh, kw, channel-in-chunk) -- the layout the kernels walk for Cin % 64 == 0
+            wp = wp.reshape(self.cout_pad, kh, kw, self.cin_pad // 64, 64).permute(0, 3, 1, 2, 4)
         packed = torch.zeros(self.cout_pad, self.k_pad, dtype=torch.float32)
         packed[:, :k] = wp.reshape(self.cout_pad, k)
         self.weight = packed.to(BF16).to(device)
@@ -76,10 +80,18 @@ class ConvProfile:
         self.records = []   # (variant, flops, start_event, end_event)
 
     @staticmethod
-    def variant(pc):
+    def variant(pc, m):
+        bk64 = pc.cin_pad % 64 == 0
+        tiles256 = (m + 255) // 256
+        if bk64 and not FORCE_GENERIC_CONV:
+            if pc.cout >= 192 and tiles256 * ((pc.cout + 255) // 256) >= 128:
+                return 'conv_dma_kernel<256,256,2,4,2>'
+            if 64 < pc.cout <= 128 and tiles256 >= 128:
+                return 'conv_dma_kernel<128,128,2,2,2>'
+            if 32 < pc.cout <= 64 and tiles256 >= 128:
+                return 'conv_dma_kernel<64,128,2,2,2>'
         tc = 128 if pc.cout > 64 else 64
-        bk = 64 if pc.cin_pad % 64 == 0 else 32
-        return f'conv_igemm_kernel<{tc},128,{bk},2,2>'
+        return f'conv_igemm_kernel<{tc},128,{64 if bk64 else 32},2,2>'
 
     def summary(self):
         torch.cuda.synchronize()
@@ -95,7 +107,10 @@ class ConvProfile:
 PROFILE = None   # set to a ConvProfile() to record
 
 
-def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0, out=None):
+FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
+
+
+def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0, out=None, pool=False):
     """x: NHWC bf16 (N,H,W,Cin_pad) -> NHWC (N,Ho,Wo,Cout) bf16 | f32."""
     _need_cuda(x, residual)
     assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
@@ -103,7 +118,8 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     assert cin == pc.cin_pad, (cin, pc.cin_pad)
     ho, wo = pc.out_hw(h, w, in_up_shift)
     if out is None:
-        out = torch.empty((n, ho, wo, pc.cout), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        oshape = (n, ho // 2, wo // 2, pc.cout) if pool else (n, ho, wo, pc.cout)
+        out = torch.empty(oshape, dtype=torch.float32 if out_f32 else BF16, device=x.device)
     hr = wr = 0
     if residual is not None:
         assert residual.dtype == BF16 and residual.is_contiguous() and residual.shape[0] == n and residual.shape[3] == pc.cout
@@ -117,12 +133,46 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
                                     pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),
                                     int(out_f32), int(in_up_shift), int(res_mode if residual is not None else 0),
-                                    hr, wr, _stream())
+                                    hr, wr, int(pool), int(FORCE_GENERIC_CONV), _stream())
     check(rc, 'cvpce_conv2d_nhwc_bf16')
     if prof is not None:
         e1.record()
         # algorithmic FLOPs: real (unpadded) channels, 2 FLOP per MAC
-        prof.records.append((prof.variant(pc), 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, e0, e1))
+        prof.records.append((prof.variant(pc, n * ho * wo), 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, e0, e1))
+    return out
+
+
+class PackedStem:
+    """Weights of conv3x3(3->64) + conv3x3(64->64) in the layout of cvpce_vgg_stem_fused (include/cvpce_amd.h)."""
+
+    def __init__(self, w1, b1, w2, b2, device='cuda'):
+        w1 = w1.detach().to(torch.float32).cpu()
+        w2 = w2.detach().to(torch.float32).cpu()
+        assert tuple(w1.shape) == (64, 3, 3, 3) and tuple(w2.shape) == (64, 64, 3, 3)
+        p1 = torch.zeros(64, 3, 4, 4)                       # (cout, kh, kw 0..3, c 0..3)
+        p1[:, :, :3, :3] = w1.permute(0, 2, 3, 1)           # (cout, kh, kw, c)
+        self.w1 = p1.reshape(64, 48).to(BF16).to(device)
+        self.w2 = w2.permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous().to(BF16).to(device)   # (tap, cout, cin)
+        self.b1 = b1.detach().to(torch.float32).to(device)
+        self.b2 = b2.detach().to(torch.float32).to(device)
+        self.flops_per_pixel = 2.0 * 64 * (27 + 576)
+
+
+def vgg_stem(x, ps):
+    """x: (N,H,W,4|8) bf16 normalised input -> (N,H/2,W/2,64) bf16 = pool(relu(conv(relu(conv(x)))))."""
+    _need_cuda(x)
+    assert x.dtype == BF16 and x.is_contiguous() and x.shape[3] in (4, 8)
+    n, h, w, c = x.shape
+    out = torch.empty((n, h // 2, w // 2, 64), dtype=BF16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(ps.w1), _p(ps.b1), _p(ps.w2), _p(ps.b2), _p(out), n, h, w, _stream()),
+          'cvpce_vgg_stem_fused')
+    if prof is not None:
+        e1.record()
+        prof.records.append(('vgg_stem_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
     return out
 
 

@@ -11,8 +11,10 @@
  * Tensor layouts
  *   activations : NHWC bf16, C % 8 == 0 (3-channel images are carried as C = 8,
  *                 channels 3..7 zero)
- *   conv weights: bf16 [Cout_pad][K_pad], K index = (kh*KW + kw)*Cin + ci,
- *                 Cout_pad % 128 == 0, K_pad % 64 == 0, zero padded
+ *   conv weights: bf16 [Cout_pad][K_pad], zero padded, Cout_pad % 256 == 0;
+ *                 Cin % 64 == 0: K index = (((ci/64)*KH + kh)*KW + kw)*64 + ci%64, K_pad % 64 == 0
+ *                                (chunk-major: the KH*KW taps of a 64-channel chunk are adjacent)
+ *                 otherwise    : K index = (kh*KW + kw)*Cin + ci, K_pad % 32 == 0
  *                 (FrozenBN / BatchNorm-eval already folded in by the host)
  */
 #ifndef CVPCE_AMD_H
@@ -33,11 +35,22 @@ extern "C" {
  *                   (GaussianLayer.forward `self.up(x)`, proposals.py:79) -- not materialised
  *   res_mode 0/1/2: none / same-size residual (Bottleneck add) / nearest-resampled
  *                   residual [N][Hr][Wr][Cout] (FPN top-down add; proposals.py:76)
- *   out_f32       : NHWC fp32 output (head logits / box regressions / gaussians) */
+ *   out_f32       : NHWC fp32 output (head logits / box regressions / gaussians)
+ *   fuse_pool2    : the following nn.MaxPool2d(2,2) is taken in the epilogue; `out` is
+ *                   [N][Ho/2][Wo/2][Cout] (VGG16 `features` conv+ReLU+pool triples)
+ *   force_generic : 1 = always use the register-staged fallback kernel (A/B tests) */
 int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res, void* out,
                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
-                           int res_mode, int Hr, int Wr, void* stream);
+                           int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
+
+/* Fused VGG16 stem: features[0:5] = conv3x3(3->64)+ReLU, conv3x3(64->64)+ReLU, MaxPool2d(2,2)
+ * (torchvision vgg cfg 'D'; reached from cvpce/models/classification.py:27,36) as one persistent kernel with
+ * both layers' weights resident in LDS.  in: NHWC bf16 with `in_cstride` (4 or 8) channels per pixel,
+ * channels 0..2 used, channel 3 zero; H, W multiples of 16.  w1: bf16 [64][48], k = kh*16 + kw*4 + c
+ * (slots kw = 3 and c = 3 zero); w2: bf16 [9][64][64] = (tap, cout, cin); out: [N][H/2][W/2][64] bf16. */
+int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
+                         const float* b2, void* out, int N, int H, int W, void* stream);
 
 /* nn.MaxPool2d (VGG 2x2 s2; ResNet stem 3x3 s2 p1), NHWC bf16 */
 int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,

@@ -57,6 +57,20 @@ CONV_CASES = [
     ('gauss_tanh', 1, 16, 40, 40, 1, 1, 1, 0, {'f32': True, 'act': 2}),
     ('deep_k', 1, 512, 9, 9, 512, 3, 1, 1, {}),
     ('ragged_m', 3, 64, 5, 3, 192, 3, 1, 1, {}),
+    # big-M shapes: routed to the LDS-DMA kernel (256x256 / 128x256 / 64x256 tiles)
+    ('dma256', 2, 64, 128, 128, 256, 3, 1, 1, {}),
+    ('dma512_deep', 1, 256, 128, 128, 512, 3, 1, 1, {}),
+    ('dma128', 2, 64, 128, 128, 128, 3, 1, 1, {}),
+    ('dma64', 2, 64, 128, 128, 64, 3, 1, 1, {}),
+    ('dma_1x1_res', 2, 256, 128, 128, 256, 1, 1, 0, {'res': 'same'}),
+    ('dma_s2', 2, 128, 256, 256, 256, 3, 2, 1, {}),
+    ('dma_ragged', 1, 64, 181, 182, 192, 3, 1, 1, {}),
+    ('dma_res_up', 2, 64, 128, 128, 256, 1, 1, 0, {'res': 'up', 'act': 0}),
+    # conv + ReLU + MaxPool2d(2,2) fused
+    ('pool_dma256', 2, 64, 128, 128, 256, 3, 1, 1, {'pool': True}),
+    ('pool_dma64', 2, 64, 128, 128, 64, 3, 1, 1, {'pool': True}),
+    ('pool_generic', 3, 32, 20, 24, 64, 3, 1, 1, {'pool': True}),
+    ('pool_generic_first', 2, 3, 36, 40, 64, 3, 1, 1, {'pool': True}),
 ]
 
 
@@ -87,9 +101,23 @@ def test_conv2d_parity(cuda, case):
         ref = F.relu(ref)
     elif act == 2:
         ref = torch.tanh(ref)
-    y = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev, in_up_shift=in_up)
+    if o.get('pool'):
+        ref = F.max_pool2d(ref, 2, 2)
+    y = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev, in_up_shift=in_up,
+                   pool=o.get('pool', False))
     torch.cuda.synchronize()
     got = nchw(y)
+    if name.startswith('dma') or name.startswith('pool_dma'):
+        # the LDS-DMA kernel and the register-staged fallback accumulate every output element in the same
+        # K order -> bit-identical results (an A/B of the two code paths on the same inputs)
+        assert ops.ConvProfile.variant(pc, ref.shape[0] * (y.shape[1] * (2 if o.get('pool') else 1)) * (y.shape[2] * (2 if o.get('pool') else 1))).startswith('conv_dma')
+        ops.FORCE_GENERIC_CONV = True
+        try:
+            y2 = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev,
+                            in_up_shift=in_up, pool=o.get('pool', False))
+        finally:
+            ops.FORCE_GENERIC_CONV = False
+        assert torch.equal(y2, y)
     assert got.shape == ref.shape
     tol = 2e-4 if o.get('f32') else 1e-2   # bf16 output rounding = 2^-8 relative
     assert rel_err(got, ref) < tol, (name, rel_err(got, ref))
@@ -316,3 +344,39 @@ def test_match_ties_lowest_index(cuda):
     Q = torch.zeros(3, 64); Q[:, 0] = 1.0
     idx = ops.match_topk(Q.to(cuda), G.to(cuda), 5).cpu()
     assert idx.equal(torch.arange(5).expand(3, 5))
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 32, 48), (1, 256, 256), (3, 16, 16)])
+def test_vgg_stem_fused_parity(cuda, n, h, w):
+    """Fused conv1_1+ReLU+conv1_2+ReLU+pool kernel against the oracle ops on the same bf16-rounded operands
+    (conv1_1's output is rounded to bf16 before conv1_2, exactly like the unfused schedule stores it)."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    x = r16(torch.randn(n, 3, h, w, generator=g))
+    w1 = torch.randn(64, 3, 3, 3, generator=g) / math.sqrt(27)
+    b1 = torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(576)
+    b2 = torch.randn(64, generator=g) * 0.1
+    mid = r16(F.relu(F.conv2d(x, r16(w1), b1, padding=1)))
+    ref = F.max_pool2d(F.relu(F.conv2d(mid, r16(w2), b2, padding=1)), 2, 2)
+    ps = ops.PackedStem(w1, b1, w2, b2, device=cuda)
+    for cstride in (8, 4):
+        xin = torch.zeros(n, h, w, cstride, dtype=BF)
+        xin[..., :3] = x.permute(0, 2, 3, 1).to(BF)
+        got = nchw(ops.vgg_stem(xin.to(cuda), ps))
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < 1e-2, rel_err(got, ref)
+    # and bit-for-bit against the unfused HIP schedule (same K order per output element is NOT guaranteed across
+    # the two kernels, so compare within one bf16 ulp instead)
+    pc1, pc2 = ops.PackedConv(w1, b1, 1, 1, device=cuda), ops.PackedConv(w2, b2, 1, 1, device=cuda)
+    xin8 = torch.zeros(n, h, w, 8, dtype=BF); xin8[..., :3] = x.permute(0, 2, 3, 1).to(BF)
+    unf = ops.conv2d(ops.conv2d(xin8.to(cuda), pc1, act=1), pc2, act=1, pool=True)
+    fused = ops.vgg_stem(xin8.to(cuda), ps)
+    assert (unf.float() - fused.float()).abs().max() <= 2 ** -7 * unf.float().abs().max()
+
+
+def test_vgg_stem_rejects_bad_shapes(cuda):
+    from cvpce_amd import ops
+    ps = ops.PackedStem(torch.zeros(64, 3, 3, 3), torch.zeros(64), torch.zeros(64, 64, 3, 3), torch.zeros(64), device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.vgg_stem(torch.zeros(1, 24, 16, 8, dtype=BF, device=cuda), ps)     # H not a multiple of 16

@@ -1,0 +1,47 @@
+"""Per-layer conv microbenchmark (dev tool): VGG16 / ResNet shapes through ops.conv2d, TFLOP/s per layer."""
+import sys, os, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cvpce_amd import ops
+
+LAYERS = {
+    # name: (N, Cin, H, W, Cout, k, stride, pad, pool)
+    'vgg1_1': (256, 3, 256, 256, 64, 3, 1, 1, False),
+    'vgg1_2': (256, 64, 256, 256, 64, 3, 1, 1, True),
+    'vgg2_1': (256, 64, 128, 128, 128, 3, 1, 1, False),
+    'vgg2_2': (256, 128, 128, 128, 128, 3, 1, 1, True),
+    'vgg3_1': (256, 128, 64, 64, 256, 3, 1, 1, False),
+    'vgg3_2': (256, 256, 64, 64, 256, 3, 1, 1, False),
+    'vgg4_1': (256, 256, 32, 32, 512, 3, 1, 1, False),
+    'vgg4_2': (256, 512, 32, 32, 512, 3, 1, 1, False),
+    'vgg5_1': (256, 512, 16, 16, 512, 3, 1, 1, False),
+    'res_c2_1x1': (8, 64, 200, 200, 256, 1, 1, 0, False),
+    'res_c3_3x3': (8, 128, 100, 100, 128, 3, 1, 1, False),
+    'head_p3': (8, 256, 100, 100, 256, 3, 1, 1, False),
+}
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--layers', default=','.join(LAYERS))
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--generic', action='store_true')
+args = ap.parse_args()
+dev = torch.device('cuda')
+ops.FORCE_GENERIC_CONV = args.generic
+for name in args.layers.split(','):
+    n, cin, h, w, cout, k, stride, pad, pool = LAYERS[name]
+    g = torch.Generator().manual_seed(0)
+    pc = ops.PackedConv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.zeros(cout), stride, pad, device=dev)
+    x = (torch.randn(n, h, w, pc.cin_pad, generator=g)).to(torch.bfloat16).to(dev)
+    for _ in range(2):
+        y = ops.conv2d(x, pc, act=1, pool=pool)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        y = ops.conv2d(x, pc, act=1, pool=pool)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    ho, wo = pc.out_hw(h, w)
+    flops = 2.0 * n * ho * wo * cout * k * k * cin
+    print(f'{name:12s} {ops.ConvProfile.variant(pc, n * ho * wo):34s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s  in {x.numel() * 2 / 1e6:7.1f} MB out {y.numel() * 2 / 1e6:7.1f} MB')
