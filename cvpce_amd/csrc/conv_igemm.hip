@@ -448,28 +448,35 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
         if (kt + 3 < nk) CVPCE_DMA4_STAGE(kt + 3, (kt + 3) & 3)
         const bf16_t* Wb = Ws + (kt & 3) * TC * BK;
         const bf16_t* Pb = Ps + (kt & 3) * TP * BK;
+        // both 16-deep fragment groups of the K-step are fetched up front; sched_barrier keeps the second
+        // group's ds_reads ahead of the first group's MFMAs (the scheduler would otherwise sink them)
+        bf16x8 af[2][MT], bfr[2][NT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int chunk = kk * 2 + lh;
-            bf16x8 af[MT], bfr[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wc * (TC / WC) + mt * 32 + lr;
-                af[mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
+                af[kk][mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int row = wp * (TP / WP) + nt * 32 + lr;
-                bfr[nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
+                bfr[kk][nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][mt], bfr[kk][nt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #undef CVPCE_DMA4_STAGE
     conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);

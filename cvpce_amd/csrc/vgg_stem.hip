@@ -111,6 +111,17 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
         pp2[nt] = oy * ST_P1 + ox;      // + kh*18 + kw per tap
     }
 
+    // biases live in registers for the whole persistent loop (a global load per tile would put an
+    // L2 round trip on the critical path of both epilogues)
+    f32x4 bias1[2][4], bias2[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias1[ct][g] = *reinterpret_cast<const f32x4*>(a.b1 + ct * 32 + 8 * g + 4 * lh);
+            bias2[ct][g] = *reinterpret_cast<const f32x4*>(a.b2 + ct * 32 + 8 * g + 4 * lh);
+        }
+
     for (; tile < a.ntiles; tile += gridDim.x) {
         const int n = tile / (a.tiles_x * a.tiles_y);
         const int rem = tile - n * (a.tiles_x * a.tiles_y);
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int co = ct * 32 + 8 * g + 4 * lh;
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(a.b1 + co);
+                        const f32x4 b = bias1[ct][g];
                         bf16x4 o;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(inside ? fmaxf(acc[ct][4 * g + j] + b[j], 0.f) : 0.f);
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        bf16x8 af[2][2], bfr[2][2];
+        bf16x8 af[3][2], bfr[3][2];
 #define ST_LOAD(S, SLOT)                                                                                       \
         {                                                                                                      \
             const int tap = (S) >> 2, kk = (S) & 3;                                                            \
@@ -183,15 +194,21 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
                 bfr[SLOT][nt] = *reinterpret_cast<const bf16x8*>(A1 + a1_off(pp2[nt] + kh * ST_P1 + kw, chunk)); \
         }
+        // fragments run TWO K-steps ahead of the MFMAs (3 register slots); sched_barrier pins that order --
+        // left alone, the scheduler sinks each ds_read group to just before its consumer and exposes the
+        // full LDS latency on every K-step
         ST_LOAD(0, 0)
+        ST_LOAD(1, 1)
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (s + 1 < 36) ST_LOAD(s + 1, (s + 1) & 1)
+            if (s + 2 < 36) ST_LOAD(s + 2, (s + 2) % 3)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][mt], bfr[s & 1][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % 3][mt], bfr[s % 3][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #undef ST_LOAD
         // epilogue: bias, 2x2 max over the quad's 4 lanes, ReLU, store the pooled pixel
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = mt * 32 + 8 * g + 4 * lh;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.b2 + co);
+                    const f32x4 b = bias2[mt][g];
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
