@@ -126,8 +126,19 @@ def main():
         ops.PROFILE = None
         name, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the figure measured
+        # by the same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (two passes, gfx950 FETCH x2
+        # correction) and committed under profiles/; null if no profile covers the kernel
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01b_pmc_hbm_traffic.json')))
+            for k, v in prof.items():
+                if name.split('<')[0] in k and name.split('<')[1].split(',')[0] in k.split('<')[1]:
+                    traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
+        except Exception:
+            traffic = None
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/)',
                     'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
                     'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4),
                     'all_conv_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
