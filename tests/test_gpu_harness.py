@@ -1,0 +1,76 @@
+"""Eval harness counterparts on the GPU: the same per-image data reaches the metric / counting
+code as in the reference's loops, checked end to end on synthetic data against the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _GP180Like:
+    def __init__(self, items, anns):
+        self.items = items
+        self.int_to_ann = list(anns)
+        self.ann_to_int = {a: i for i, a in enumerate(anns)}
+
+    def __iter__(self):
+        return iter(self.items)
+
+    def __len__(self):
+        return len(self.items)
+
+
+def test_eval_dihe_counts_topk(cuda):
+    """classification_eval.py:6-56: paste gallery products into a shelf image, crop the ground-truth boxes, top-k accuracy."""
+    from cvpce_amd import classification_eval, synthetic
+    enc = synthetic.synthetic_macvgg(seed=1).to(cuda)
+    gal = synthetic.gallery_images(12, seed=5)
+    anns = [f'p{i}' for i in range(12)]
+    shelf = torch.full((3, 300, 1100), 0.3)
+    boxes, targets = [], []
+    for j, i in enumerate((3, 7, 0, 11)):
+        shelf[:, 20:276, 10 + j * 270:266 + j * 270] = (gal[i] + 1) / 2      # exact 256x256 paste -> identity crop
+        boxes.append([10 + j * 270, 20, 266 + j * 270, 276]); targets.append(anns[i])
+    testset = [(shelf, targets, torch.tensor(boxes))]
+    acc = classification_eval.eval_dihe(enc, synthetic.TensorGallery(gal, anns), testset, batch_size=8, k=(1, 3))
+    assert acc == {1: 1.0, 3: 1.0}
+    # a wrong annotation is counted as a miss for k=1
+    testset = [(shelf, ['p3', 'p7', 'p0', 'p1'], torch.tensor(boxes))]
+    acc = classification_eval.eval_dihe(enc, synthetic.TensorGallery(gal, anns), testset, batch_size=8, k=(1,))
+    assert acc == {1: 0.75}
+
+
+def test_evaluate_gln_sync_matches_oracle_harness(cuda):
+    """proposals_eval.py:19-48: GPU detections vs targets through calculate_metrics == oracle detections through it."""
+    from cvpce_amd import metrics, proposals_eval, synthetic
+    from oracle import gln as og
+    model = synthetic.synthetic_gln(seed=0, detections_per_img=60)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(cuda)
+    imgs = [synthetic.shelf_image(s, 512, 512) for s in (21, 22)]
+    ref = [og.gln_forward([i], sd, detections_per_img=60)[0] for i in imgs]
+    # ground truth := the oracle's 30 best boxes per image
+    dataset = [(i, {'boxes': r['boxes'][:30]}) for i, r in zip(imgs, ref)]
+    got = proposals_eval.evaluate_gln_sync(model, dataset, thresholds=(0.5, 0.75), batch_size=1)
+    want = metrics.calculate_metrics([d[1]['boxes'] for d in dataset], [r['boxes'] for r in ref], [r['scores'] for r in ref], (0.5, 0.75))
+    for thr in (0.5, 0.75):
+        assert 'raw' not in got[thr]
+        assert abs(float(got[thr]['ap']) - float(want[thr]['ap'])) < 0.05          # "mAP within tolerance of the oracle path"
+        assert abs(float(got[thr]['ar_300']) - float(want[thr]['ar_300'])) < 0.05
+        assert float(want[thr]['ap']) > 0.5
+
+
+def test_evaluate_detections_class_bucketing(cuda):
+    """detection_eval.py:6-49: no confidence filter, unknown labels -> class -1 (excluded per class, kept in 'all')."""
+    from cvpce_amd import detection_eval, synthetic
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=12).to(cuda)
+    enc = synthetic.synthetic_macvgg(seed=1).to(cuda)
+    gal = synthetic.gallery_images(6, seed=9)
+    gallery_anns = ['a', 'b', 'c', 'zz_unknown', 'a', 'b']              # 'zz_unknown' is not a test-set class
+    img = synthetic.shelf_image(31, 512, 512)
+    pred = det([img.to(cuda)])[0]
+    tset = _GP180Like([(img, {'boxes': pred['boxes'][:6].cpu(), 'labels': torch.tensor([0, 1, 2, 0, 1, 2])})], ['a', 'b', 'c'])
+    per_class, overall = detection_eval.evaluate_detections(det, enc, tset, synthetic.TensorGallery(gal, gallery_anns),
+                                                            proposal_batch_size=1, classification_batch_size=8)
+    assert set(per_class) <= {0, 1, 2} and 0.5 in overall and 'ap' in overall[0.5]
+    m = detection_eval.mean_average_metrics(per_class, (0.5,))
+    assert 0.0 <= float(m[0.5]['map']) <= 1.0
