@@ -37,34 +37,39 @@ def parse():
 
 
 def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
-    """The oracle (a port: plain fp32 torch CPU ops restating the reference) on a bounded sample of the
-    same workload, on this box's host cores: 1 shelf image through the detector, 4 crops through the
-    embedder, 200 queries through the reference's literal matcher (Q capped at 32 per call like
-    production.py's batch loop); extrapolated to one image with P = dpi proposals."""
+    """The oracle (a port: plain fp32 torch CPU ops restating the reference) on a bounded sample of the same workload,
+    on this box's host cores (about 10-30 s of CPU work): 3 shelf images through the detector, 64 crops through
+    crop+embed, one image's worth of queries through the reference's literal matcher in batches of 32 (production.py's
+    batch loop); extrapolated to one image with P = dpi proposals."""
     from oracle import gln as og, macvgg as ovgg, crop as ocrop, match as omatch
     from cvpce_amd import synthetic
     cores = min(16, os.cpu_count() or 1)   # the GPU box's CPU share for one GPU; more threads only oversubscribe
     torch.set_num_threads(cores)
-    img = synthetic.shelf_image(0, image_size, image_size)
+    n_img, n_crop = 3, 64
+    imgs = [synthetic.shelf_image(s, image_size, image_size) for s in range(n_img)]
     t = time.perf_counter()
-    res = og.gln_forward([img], det_sd, detections_per_img=dpi)[0]
-    t_det = time.perf_counter() - t
-    boxes = res['boxes'][res['scores'] > 0.5][:4]
-    if len(boxes) < 4:
-        boxes = torch.tensor([[10., 10., 300., 400.]] * 4)
+    res = [og.gln_forward([i], det_sd, detections_per_img=dpi)[0] for i in imgs]
+    t_det = (time.perf_counter() - t) / n_img
+    boxes = res[0]['boxes'][res[0]['scores'] > 0.5][:n_crop]
+    if len(boxes) < n_crop:
+        boxes = torch.tensor([[10., 10., 300., 400.]] * n_crop)
     t = time.perf_counter()
-    crops = ocrop.crop_boxes(img, boxes)
-    emb = ovgg.macvgg_forward(ocrop.scale_to_tanh(crops), enc_sd)
-    t_embed4 = time.perf_counter() - t
-    q = emb.repeat(8, 1)   # 32 queries
+    embs = []
+    for i in range(0, n_crop, 32):
+        crops = ocrop.crop_boxes(imgs[0], boxes[i:i + 32])
+        embs.append(ovgg.macvgg_forward(ocrop.scale_to_tanh(crops), enc_sd))
+    t_embed = (time.perf_counter() - t) / n_crop
+    q = torch.cat(embs)[:32]
+    n_batches = (dpi + 31) // 32
     t = time.perf_counter()
-    omatch.nearest_neighbors_literal(gallery_emb, q, 1)
-    t_match32 = time.perf_counter() - t
-    per_image = t_det + t_embed4 / 4 * dpi + t_match32 / 32 * dpi
+    for _ in range(n_batches):
+        omatch.nearest_neighbors_literal(gallery_emb, q, 1)
+    t_match = time.perf_counter() - t
+    per_image = t_det + t_embed * dpi + t_match
     return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle (fp32 torch CPU restatement): 1 image {image_size}x{image_size} detector {t_det:.2f}s + '
-                      f'4 crops crop+embed {t_embed4:.2f}s + literal matcher 32 queries x {len(gallery_emb)} gallery '
-                      f'{t_match32:.2f}s, extrapolated to P={dpi} proposals/image'}
+            'sample': f'oracle (fp32 torch CPU restatement): detector {n_img} images {image_size}x{image_size} at {t_det:.2f} s/image + '
+                      f'crop+embed {n_crop} crops at {t_embed * 1e3:.0f} ms/crop + literal matcher {n_batches} x 32 queries x '
+                      f'{len(gallery_emb)} gallery {t_match:.2f} s; extrapolated to P={dpi} proposals/image'}
 
 
 def main():

@@ -9,7 +9,7 @@ import os
 from ctypes import c_int, c_float, c_void_p, c_size_t, c_longlong, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcvpce_hip.so')
+LIB_PATH = os.environ.get('CVPCE_LIB') or os.path.join(_HERE, 'libcvpce_hip.so')   # CVPCE_LIB: dev-only A/B builds
 
 
 class HipLibraryMissing(ImportError):

@@ -34,8 +34,15 @@
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 
+// compile-time timing experiments (never set in the shipped library): 1 no DMA in the K loop, 2 no barrier,
+// 4 no pixel DMA, 8 no MFMA.  Built by tools/ablate.sh into side libraries selected with CVPCE_LIB.
+#ifndef CVPCE_DBG
+#define CVPCE_DBG 0
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
+typedef __attribute__((address_space(3))) char lds_char;
 
 __device__ __attribute__((aligned(16))) unsigned int cvpce_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -54,6 +61,7 @@ struct ConvArgs {
     int res_mode, Hr, Wr;
     int pool;
     int tiles_p, tiles_c;
+    unsigned in_bytes, wgt_bytes;   // buffer-descriptor extents of `in` / `wgt` (LDS-DMA bounds check = zero fill)
 };
 
 // M index -> (image, oy, ox).  Row-major, or 2x2-quad order when the pool is fused.
@@ -350,9 +358,10 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma_kernel(ConvArgs a
 // K-steps (4 x 32 KiB at 256x256): stage t+3 is issued while stage t computes, the wave waits with
 // a COUNTED vmcnt (never 0 in steady state) and a raw s_barrier (a __syncthreads() would drain
 // vmcnt to 0).  K order: (64-channel chunk, kh, kw, 32-channel half, channel).
-template <int TC, int TP, int WC, int WP, int MINW>
+template <int TC, int TP, int WC, int WP, int MINW, int NS>
 __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs a) {
-    constexpr int BK = 32, NS = 4;
+    constexpr int BK = 32;
+    static_assert(NS == 3 || NS == 4, "ring depth");
     constexpr int NW = WC * WP;
     constexpr int WJ = TC / (16 * NW);     // weight DMA pieces per wave per K-step (16 rows of 64 B each)
     constexpr int PJ = TP / (16 * NW);
@@ -376,50 +385,66 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
     const int lrow = wid * 16 + (lane >> 2);
     const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
 
-    const int Hl = a.H << a.in_up_shift, Wl = a.W << a.in_up_shift;
-    int pbase[PJ], piy[PJ], pix[PJ];
+    // Per-lane, K-invariant part of every pixel-piece address, computed ONCE: byte offset of (image, oy*stride,
+    // ox*stride, lane's 8-channel slice) and a bit mask of the taps that fall inside the image.  The tap / channel
+    // walk of the K loop is wave-uniform (SALU); each DMA piece then costs one v_add + one v_cndmask of address math.
+    // (Ablation, VGG conv4_2: with the per-piece index recomputation the DMA stage cost 0.31 ms of a 1.37 ms launch.)
+    unsigned poff[PJ], pmask[PJ];
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int m = tile_p * TP + j * 16 * NW + lrow;
+        poff[j] = 0u;
+        pmask[j] = 0u;
         if (m < a.M) {
             int img, oy, ox;
             decode_m(a, m, img, oy, ox);
-            piy[j] = oy * a.stride - a.pad;
-            pix[j] = ox * a.stride - a.pad;
-            pbase[j] = img * a.H * a.W;
-        } else {
-            piy[j] = -(1 << 28);
-            pix[j] = 0;
-            pbase[j] = 0;
+            const int y0 = oy * a.stride, x0 = ox * a.stride;
+            poff[j] = (unsigned)((((size_t)(img * a.H + y0) * a.W + x0) * a.Cin + lchunk * 8) * 2);
+            for (int t = 0; t < a.KH * a.KW; ++t) {
+                const int iy = y0 - a.pad + t / a.KW, ix = x0 - a.pad + t % a.KW;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) pmask[j] |= 1u << t;
+            }
         }
     }
-    int ci = lchunk * 8, kh = 0, kw = 0, half = 0;     // channel = ci + 32*half
-    const bf16_t* wsrc = a.wgt + (size_t)(tile_c * TC + lrow) * a.K_pad + lchunk * 8;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(cvpce_zero_page);
+    // wave-uniform K walk: (64-channel chunk, kh, kw, 32-channel half)
+    int kh = 0, kw = 0, half = 0, cbase = 0, tapi = 0;
+    int tap_off = ((0 - a.pad) * a.W + (0 - a.pad)) * a.Cin * 2;     // byte shift of tap (kh,kw), may be negative
 
+    // LDS-DMA through BUFFER instructions (`buffer_load_dwordx4 ... offen lds`), not `global_load_lds`: the latter is
+    // FLAT-encoded, and hipcc then treats every later LDS wait as lgkmcnt(0) (flat ops may return out of order), which
+    // serialises the fragment prefetch.  A buffer descriptor also gives the zero fill for free: an out-of-range
+    // offset (padding halo, ragged rows, K padding) returns 0 -- no zero page, no select on a 64-bit pointer.
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    unsigned woff[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+        woff[j] = (unsigned)(((size_t)(tile_c * TC + lrow + j * 16 * NW) * a.K_pad + lchunk * 8) * 2);
 #define CVPCE_DMA4_STAGE(KT, BUF)                                                                              \
     {                                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < WJ; ++j) {                                                       \
-            const bf16_t* src = wsrc + (size_t)j * 16 * NW * a.K_pad + (KT) * BK;                              \
-            __builtin_amdgcn_global_load_lds((gbl_void*)src,                                                   \
-                (lds_void*)(Ws + (BUF) * TC * BK + (j * 16 * NW + wid * 16) * BK), 16, 0, 0);                  \
-        }                                                                                                      \
-        const int ch = ci + 32 * half;                                                                         \
-        const bool tap_ok = ch < a.Cin;                                                                        \
+        const int kbyte = (KT) * (BK * 2);                                                                     \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j)                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w,                                                    \
+                (lds_void*)(Ws + (BUF) * TC * BK + (j * 16 * NW + wid * 16) * BK), 16, (int)woff[j], kbyte, 0, 0); \
+        const int uni = tap_off + (cbase + 32 * half) * 2;                                                     \
+        const bool ch_ok = cbase < a.Cin;                                                                      \
         _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                                                       \
-            const int iy = piy[j] + kh, ix = pix[j] + kw;                                                      \
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;              \
-            const size_t off =                                                                                 \
-                (size_t)(pbase[j] + (iy >> a.in_up_shift) * a.W + (ix >> a.in_up_shift)) * a.Cin + ch;         \
-            const bf16_t* src = ok ? a.in + off : zero;                                                        \
-            __builtin_amdgcn_global_load_lds((gbl_void*)src,                                                   \
-                (lds_void*)(Ps + (BUF) * TP * BK + (j * 16 * NW + wid * 16) * BK), 16, 0, 0);                  \
+            const bool ok = ch_ok && ((pmask[j] >> tapi) & 1u);                                                \
+            if (!(CVPCE_DBG & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p,                              \
+                (lds_void*)(Ps + (BUF) * TP * BK + (j * 16 * NW + wid * 16) * BK), 16,                         \
+                (int)(ok ? poff[j] + (unsigned)uni : 0xFFFFFFF0u), 0, 0, 0);                                   \
         }                                                                                                      \
         half ^= 1;                                                                                             \
         if (half == 0) {                                                                                       \
+            ++tapi;                                                                                            \
+            tap_off += a.Cin * 2;                                                                              \
             if (++kw == a.KW) {                                                                                \
                 kw = 0;                                                                                        \
-                if (++kh == a.KH) { kh = 0; ci += 64; }                                                        \
+                tap_off += (a.W - a.KW) * a.Cin * 2;                                                           \
+                if (++kh == a.KH) {                                                                            \
+                    kh = 0; tapi = 0; cbase += 64;                                                             \
+                    tap_off = ((0 - a.pad) * a.W + (0 - a.pad)) * a.Cin * 2;                                   \
+                }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -433,51 +458,86 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = a.K_pad / BK;
-    // prologue: three stages in flight
+    // Software pipeline over 16-deep fragment groups (two per stage).  The ds_reads of group g+1 are issued
+    // BEFORE the MFMAs of group g and the stage hand-off (counted vmcnt + barrier + next DMA issue) sits between the
+    // two MFMA groups of a stage, so the matrix pipe keeps draining 8 queued MFMAs while the wave waits, syncs and
+    // issues DMA.  (Ablation on VGG conv4_2: fragment reads + barrier with neither DMA nor MFMA took 0.72 ms of a
+    // 1.43 ms launch when they were serialised with the MFMAs.)
+    //   stage s lives in ring slot s & 3; when MFMA(kt, group 1) is issued, stage kt+1 must be visible (its group-0
+    //   fragments are being fetched) and stages kt+2, kt+3 are in flight.
     CVPCE_DMA4_STAGE(0, 0)
     if (nk > 1) CVPCE_DMA4_STAGE(1, 1)
-    if (nk > 2) CVPCE_DMA4_STAGE(2, 2)
+    if (NS == 4 && nk > 2) CVPCE_DMA4_STAGE(2, 2)
     const int lr = lane & 31, lh = lane >> 5;
+    int wrow[MT], prow[NT];       // byte-free row bases and swizzle terms of this lane's fragments
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wrow[mt] = wc * (TC / WC) + mt * 32 + lr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) prow[nt] = wp * (TP / WP) + nt * 32 + lr;
+    bf16x8 af[2][MT], bfr[2][NT];
+    // Fragment reads are hand-issued (`ds_read_b128` in inline asm) and hand-counted: hipcc's waitcnt pass falls back to
+    // lgkmcnt(0) for LDS reads that are pending across the loop back-edge or sit next to LDS-DMA, which would make
+    // every MFMA group wait for the group that was only just prefetched.  Inline asm hides the reads from that pass;
+    // `s_waitcnt lgkmcnt(N)` + sched_barrier below are the only LDS waits in the loop (cdna_hip_programming.md 5.4 r18).
+    const unsigned lds_w0 = (unsigned)(size_t)(lds_char*)Ws, lds_p0 = (unsigned)(size_t)(lds_char*)Ps;
+    unsigned woffb[MT], poffb[NT], wsw[MT], psw[NT];      // row byte offsets and swizzle terms of this lane's fragments
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { woffb[mt] = wrow[mt] * (BK * 2); wsw[mt] = (wrow[mt] >> 2) & 3; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { poffb[nt] = prow[nt] * (BK * 2); psw[nt] = (prow[nt] >> 2) & 3; }
+#define CVPCE_FRAGS(SLOT, STAGE, KK)                                                                           \
+    {                                                                                                          \
+        const unsigned wb_ = lds_w0 + ((STAGE) % NS) * (TC * BK * 2), pb_ = lds_p0 + ((STAGE) % NS) * (TP * BK * 2); \
+        const unsigned chunk = (KK) * 2 + lh;                                                                  \
+        if (!(CVPCE_DBG & 16) || (STAGE) == 0) {                                                               \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[SLOT][mt]) : "v"(wb_ + woffb[mt] + ((chunk ^ wsw[mt]) << 4))); \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                      \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[SLOT][nt]) : "v"(pb_ + poffb[nt] + ((chunk ^ psw[nt]) << 4))); \
+        }                                                                                                      \
+    }
+#define CVPCE_MFMAS(SLOT)                                                                                      \
+    {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        if (!(CVPCE_DBG & 8)) {                                                                                \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SLOT][mt], bfr[SLOT][nt], acc[mt][nt], 0, 0, 0); \
+        }                                                                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    }
+    // stage 0 becomes visible; fetch its first fragment group
+    if (NS == 4 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    CVPCE_FRAGS(0, 0, 0)
     for (int kt = 0; kt < nk; ++kt) {
-        // retire stage kt: stages kt+1, kt+2 may stay in flight (NP pieces each)
-        const int ahead = nk - 1 - kt;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // stage kt landed for every wave; everyone is done with stage kt-1's buffer
-        if (kt + 3 < nk) CVPCE_DMA4_STAGE(kt + 3, (kt + 3) & 3)
-        const bf16_t* Wb = Ws + (kt & 3) * TC * BK;
-        const bf16_t* Pb = Ps + (kt & 3) * TP * BK;
-        // both 16-deep fragment groups of the K-step are fetched up front; sched_barrier keeps the second
-        // group's ds_reads ahead of the first group's MFMAs (the scheduler would otherwise sink them)
-        bf16x8 af[2][MT], bfr[2][NT];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int chunk = kk * 2 + lh;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int row = wc * (TC / WC) + mt * 32 + lr;
-                af[kk][mt] = *reinterpret_cast<const bf16x8*>(Wb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int row = wp * (TP / WP) + nt * 32 + lr;
-                bfr[kk][nt] = *reinterpret_cast<const bf16x8*>(Pb + row * BK + ((chunk ^ ((row >> 2) & 3)) * 8));
-            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // group 0 (issued one MFMA group ago) has landed
+        __builtin_amdgcn_sched_barrier(0);
+        CVPCE_FRAGS(1, kt, 1)                       // group 1 of this stage, in flight under MFMA group 0
+        __builtin_amdgcn_sched_barrier(0);
+        CVPCE_MFMAS(0)
+        __builtin_amdgcn_sched_barrier(0);
+        // hand-off: stage kt+1 must have landed for every wave; slot (kt+NS-1)%NS == (kt-1)%NS is free for the next DMA.
+        // Stages kt+2 .. kt+NS-2 (NS-3 of them) may stay in flight across the wait.
+        if (kt + 1 < nk) {
+            const int ahead = nk - 2 - kt;
+            if (NS == 4 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(CVPCE_DBG & 2)) __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk && !(CVPCE_DBG & 1)) CVPCE_DMA4_STAGE(kt + NS - 1, (kt + NS - 1) % NS)
+            CVPCE_FRAGS(0, kt + 1, 0)               // group 0 of the next stage, in flight under MFMA group 1
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");   // group 1 landed; the MT+NT newer reads stay in flight
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][mt], bfr[kk][nt], acc[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
+        CVPCE_MFMAS(1)
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef CVPCE_FRAGS
+#undef CVPCE_MFMAS
 #undef CVPCE_DMA4_STAGE
     conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
@@ -633,21 +693,21 @@ static int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
-template <int TC, int TP, int WC, int WP, int MINW>
+template <int TC, int TP, int WC, int WP, int MINW, int NS>
 static int launch_conv_dma4(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_p = (a.M + TP - 1) / TP;
     a.tiles_c = (a.Cout + TC - 1) / TC;
-    const size_t smem = (size_t)4 * (TC + TP) * 32 * sizeof(bf16_t);
+    const size_t smem = (size_t)NS * (TC + TP) * 32 * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma4_kernel<TC, TP, WC, WP, MINW>,
+        if (hipFuncSetAttribute((const void*)conv_dma4_kernel<TC, TP, WC, WP, MINW, NS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     dim3 grid(a.tiles_p * a.tiles_c);
-    hipLaunchKernelGGL((conv_dma4_kernel<TC, TP, WC, WP, MINW>), grid, dim3(WC * WP * 64), smem, stream, a);
+    hipLaunchKernelGGL((conv_dma4_kernel<TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();
 }
 
@@ -676,6 +736,8 @@ extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const flo
     a.Ho = Ho; a.Wo = Wo; a.K_pad = K_pad; a.M = N * Ho * Wo; a.relu = act; a.out_f32 = out_f32;
     a.in_up_shift = in_up_shift; a.res_mode = res_mode; a.Hr = Hr; a.Wr = Wr; a.pool = fuse_pool2 ? 1 : 0;
     a.tiles_p = a.tiles_c = 0;
+    a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+    a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     hipStream_t s = (hipStream_t)stream;
     const bool bk64 = (Cin % 64 == 0);
     // LDS-DMA workhorse: K-step 64 within one tap, and enough pixel tiles to fill 256 CUs.
@@ -684,7 +746,8 @@ extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const flo
     const long long tiles256 = ((long long)a.M + 255) / 256;
     if (bk64 && force_generic != 1) {
         if (Cout >= 192 && tiles256 * ((Cout + 255) / 256) >= 128)
-            return (force_generic == 2) ? launch_conv_dma<256, 256, 2, 4, 2>(a, s) : launch_conv_dma4<256, 256, 2, 4, 2>(a, s);
+            return (force_generic == 2 || in_up_shift || KH * KW > 32) ? launch_conv_dma<256, 256, 2, 4, 2>(a, s)
+                                                                        : launch_conv_dma4<256, 256, 2, 4, 2, 4>(a, s);
         if (Cout > 64 && Cout <= 128 && tiles256 >= 128) return launch_conv_dma<128, 128, 2, 2, 2>(a, s);
         if (Cout > 32 && Cout <= 64 && tiles256 >= 128) return launch_conv_dma<64, 128, 2, 2, 2>(a, s);
     }

@@ -85,7 +85,7 @@ class ConvProfile:
         tiles256 = (m + 255) // 256
         if bk64 and not FORCE_GENERIC_CONV:
             if pc.cout >= 192 and tiles256 * ((pc.cout + 255) // 256) >= 128:
-                return 'conv_dma4_kernel<256,256,2,4,2>'
+                return 'conv_dma4_kernel<256,256,2,4,2,4>'
             if 64 < pc.cout <= 128 and tiles256 >= 128:
                 return 'conv_dma_kernel<128,128,2,2,2>'
             if 32 < pc.cout <= 64 and tiles256 >= 128:
@@ -133,7 +133,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
                                     pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),
                                     int(out_f32), int(in_up_shift), int(res_mode if residual is not None else 0),
-                                    hr, wr, int(pool), int(FORCE_GENERIC_CONV), _stream())
+                                    hr, wr, int(pool), int(FORCE_GENERIC_CONV), _stream())   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
     check(rc, 'cvpce_conv2d_nhwc_bf16')
     if prof is not None:
         e1.record()

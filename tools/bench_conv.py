@@ -23,10 +23,12 @@ LAYERS = {
 ap = argparse.ArgumentParser()
 ap.add_argument('--layers', default=','.join(LAYERS))
 ap.add_argument('--iters', type=int, default=10)
-ap.add_argument('--generic', action='store_true')
+ap.add_argument('--generic', type=int, default=0)
+ap.add_argument('--dbg', type=int, default=0)
 args = ap.parse_args()
 dev = torch.device('cuda')
 ops.FORCE_GENERIC_CONV = args.generic
+
 for name in args.layers.split(','):
     n, cin, h, w, cout, k, stride, pad, pool = LAYERS[name]
     g = torch.Generator().manual_seed(0)
