@@ -78,7 +78,7 @@ def main():
     rank, local_rank, world = cdist.init()
     if world != args.gpus and world > 1:
         args.gpus = world
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
     torch.cuda.set_device(dev)
     from cvpce_amd import ops, production, synthetic
 

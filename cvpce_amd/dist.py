@@ -23,7 +23,7 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('CVPCE_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -48,11 +48,13 @@ def all_gather_rows(local, total_rows, rank, world):
         return local
     sizes = [shard_range(total_rows, r, world) for r in range(world)]
     max_rows = max(e - s for s, e in sizes)
-    pad = torch.zeros((max_rows, local.shape[1]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
+    dev = local.device
+    stage = torch.device('cpu') if dist.get_backend() == 'gloo' else dev   # gloo rehearsals stage through host memory
+    pad = torch.zeros((max_rows, local.shape[1]), dtype=local.dtype, device=stage)
+    pad[:local.shape[0]] = local.to(stage)
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return torch.cat([o[:e - s] for o, (s, e) in zip(out, sizes)])
+    return torch.cat([o[:e - s] for o, (s, e) in zip(out, sizes)]).to(dev)
 
 
 def build_gallery_sharded(embed_fn, gallery_images, rank, world):
@@ -65,7 +67,7 @@ def build_gallery_sharded(embed_fn, gallery_images, rank, world):
 def max_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
