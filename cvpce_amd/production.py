@@ -132,6 +132,47 @@ class Classifier:
         return res
 
 
+class PlanogramComparator:
+    """production.py:76-116: graph matching -> RANSAC homography -> per-label IoU matching -> optional re-classification
+    of the expected-but-undetected positions (a second trip through the crop / embed / match kernels)."""
+
+    def __init__(self, graph_threshold=0.5):
+        self.graph_threshold = graph_threshold
+
+    def compare(self, expected, actual, image=None, classifier=None):
+        from . import planograms
+        reproj_threshold = 10 if image is None else min(image.shape[1:]) * 0.01
+        if not len(actual['boxes']):
+            return 0 if len(expected['boxes']) else 1
+        ge = expected['graph'] if 'graph' in expected else planograms.build_graph(expected['boxes'], expected['labels'],
+                                                                                  self.graph_threshold)
+        ga = planograms.build_graph(actual['boxes'], actual['labels'], self.graph_threshold)
+        matching = planograms.large_common_subgraph(ge, ga)
+        if not len(matching):
+            return 0
+        found, missing_indices, missing_positions, missing_labels = planograms.finalize_via_ransac(
+            matching, expected['boxes'], actual['boxes'], expected['labels'], actual['labels'],
+            reproj_threshold=reproj_threshold)
+        if found is None:                       # no homography (production.py:98-99)
+            return len(matching) / len(expected['boxes'])
+        if classifier is not None and image is not None and len(missing_positions):
+            h, w = image.shape[1:]
+            pos = missing_positions.clone()
+            pos[:, 0::2] = pos[:, 0::2].clamp(min=0, max=w)
+            pos[:, 1::2] = pos[:, 1::2].clamp(min=0, max=h)
+            valid = (pos[:, 2] - pos[:, 0] > 1) & (pos[:, 3] - pos[:, 1] > 1)
+            if not valid.any():
+                return found.sum() / len(found)
+            idx, pos = missing_indices[valid], pos[valid]
+            lbls = [l for l, v in zip(missing_labels, valid) if v]
+            img = image.to(device=classifier.device, dtype=torch.float32).contiguous()
+            crops = ops.crop_resize(img, pos.to(classifier.device), datautils.CLASSIFICATION_IMAGE_SIZE, mode=0)
+            for i, want, got in zip(idx, lbls, classifier.classify(crops)):
+                if want == got[0]:
+                    found[i] = True
+        return found.sum() / len(found)
+
+
 class PlanogramEvaluator:
     """production.py:118-129 glue; `planogram_comparator` is any object with `.compare(expected, actual, image, classifier)`."""
 

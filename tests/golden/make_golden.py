@@ -188,6 +188,41 @@ def main():
     torch.save({'targets': T, 'predictions': P, 'confidences': C,
                 'kat_result': {k: v for k, v in res[0.5].items()}, 'random': rnd},
                os.path.join(HERE, 'metrics.pt'))
+    # ---- 4. planogram graph logic (cvpce/planograms.py:12-132; needs networkx only) --------------
+    sys.modules['cv2'].findHomography = None
+    sys.modules['cv2'].RANSAC = 8
+    from cvpce import planograms as ref_plano
+
+    def grid(rows, cols, seed, jitter=4.0, drop=(), w=60.0, h=90.0, gap=12.0):
+        g = torch.Generator().manual_seed(seed)
+        boxes, labels = [], []
+        for r in range(rows):
+            for c in range(cols):
+                if (r, c) in drop:
+                    continue
+                x = c * (w + gap) + float(torch.randn(1, generator=g)) * jitter
+                y = r * (h + gap) + float(torch.randn(1, generator=g)) * jitter
+                boxes.append([x, y, x + w, y + h])
+                labels.append(f'sku{(r * 3 + c * 5) % 7}')
+        return torch.tensor(boxes), labels
+
+    def edges(gr):
+        return sorted((int(a), int(b), d['dir'], float(d['weight'])) for a, b, d in gr.edges(data=True))
+
+    plano = []
+    for seed, (rows, cols, drop) in enumerate([(3, 4, ()), (4, 6, ((1, 2),)), (2, 5, ((0, 0), (1, 4))), (5, 5, ())]):
+        eb, el = grid(rows, cols, 40 + seed, jitter=0.0)                 # planogram: perfect grid
+        ab, al = grid(rows, cols, 50 + seed, jitter=5.0, drop=drop)      # detections: jittered, some missing
+        ab = ab * 1.7 + torch.tensor([30.0, 12.0, 30.0, 12.0])           # different scale / offset
+        ge = ref_plano.build_graph(eb, el, 0.5)
+        ga = ref_plano.build_graph(ab, al, 0.5)
+        hyp = ref_plano.build_hypotheses(ge, ga)
+        match = ref_plano.large_common_subgraph(ge, ga)
+        plano.append({'expected_boxes': eb, 'expected_labels': el, 'actual_boxes': ab, 'actual_labels': al,
+                      'expected_edges': edges(ge), 'actual_edges': edges(ga),
+                      'hypotheses': [(float(sc), int(a), int(b)) for sc, a, b in hyp],
+                      'matching': sorted((int(a), int(b)) for a, b in match)})
+    torch.save(plano, os.path.join(HERE, 'planograms.pt'))
     print('golden fixtures written to', HERE)
 
 

@@ -74,3 +74,37 @@ def test_evaluate_detections_class_bucketing(cuda):
     assert set(per_class) <= {0, 1, 2} and 0.5 in overall and 'ap' in overall[0.5]
     m = detection_eval.mean_average_metrics(per_class, (0.5,))
     assert 0.0 <= float(m[0.5]['map']) <= 1.0
+
+
+def test_planogram_evaluator_end_to_end(cuda):
+    """production.py:118-129 + :76-116: proposals -> classify -> graph match -> homography -> the product the detector
+    missed is re-classified from the image at its projected planogram position (second trip through K9-K11)."""
+    from cvpce_amd import ops, production, synthetic
+    enc = synthetic.synthetic_macvgg(seed=1).to(cuda)
+    gal = synthetic.gallery_images(8, seed=17)
+    anns = [f'sku{i}' for i in range(8)]
+    clf = production.Classifier(enc, synthetic.TensorGallery(gal, anns), device=cuda, emb_device=cuda, batch_size=8,
+                                match_dtype=torch.float32)
+    rows, cols, size, gap = 2, 4, 256, 16      # pasted at gallery resolution: a random-weight embedder is not scale invariant
+    shelf = torch.full((3, rows * (size + gap) + gap, cols * (size + gap) + gap), 0.5)
+    boxes, labels = [], []
+    for r in range(rows):
+        for c in range(cols):
+            i = r * cols + c
+            x, y = gap + c * (size + gap), gap + r * (size + gap)
+            shelf[:, y:y + size, x:x + size] = (gal[i] + 1) / 2
+            boxes.append([float(x), float(y), float(x + size), float(y + size)]); labels.append(anns[i])
+    boxes = torch.tensor(boxes)
+    planogram = {'boxes': boxes / 2.0, 'labels': labels}         # planogram drawn at half scale
+
+    class _Detector:                                              # stands in for GLN: every product except #5
+        device = cuda
+        def generate_proposals_and_images(self, image):
+            keep = torch.tensor([i for i in range(len(boxes)) if i != 5])
+            b = boxes[keep].to(cuda)
+            return b, ops.crop_resize(image.to(cuda).contiguous(), b, 256, mode=0)
+
+    ev = production.PlanogramEvaluator(_Detector(), clf, production.PlanogramComparator())
+    assert float(ev.evaluate(shelf, planogram)) == 1.0            # missing detection recovered by re-classification
+    blank = shelf.clone(); blank[:, int(boxes[5, 1]):int(boxes[5, 3]), int(boxes[5, 0]):int(boxes[5, 2])] = 0.5
+    assert abs(float(ev.evaluate(blank, planogram)) - 7 / 8) < 1e-6    # product really absent -> non-compliant slot
