@@ -33,6 +33,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
+// max over the 2x2 quad formed by 4 adjacent lanes, with DPP quad_perm (one VALU op per step; __shfl_xor would go
+// through ds_bpermute = an LDS round trip per value)
+__device__ __forceinline__ float quad_max(float x) {
+    float y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x = fmaxf(x, y);
+    y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));         // quad_perm [2,3,0,1]
+    return fmaxf(x, y);
+}
+
 static inline int cvpce_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CVPCE_OK : CVPCE_ERR_LAUNCH;

@@ -132,9 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float x = v[j];
-                        x = fmaxf(x, __shfl_xor(x, 1));
-                        x = fmaxf(x, __shfl_xor(x, 2));
+                        float x = quad_max(v[j]);
                         if (a.relu == 1) x = fmaxf(x, 0.f);
                         v[j] = x;
                     }
@@ -166,6 +164,87 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
                 }
+            }
+        }
+    }
+}
+
+// Epilogue for the 16x16x32 accumulator layout: lane owns pixel (lane&15) of each 16-pixel block and channels
+// 4*(lane>>4) + {0..3} of each 16-channel block.
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[MT][NT], int c_base, int p_base, int lane) {
+    const int lp = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int m = p_base + nt * 16 + lp;
+        const bool m_ok = m < a.M;
+        size_t res_pix = 0;
+        if (a.res_mode == 1) {
+            res_pix = (size_t)m;
+        } else if (a.res_mode == 2 && m_ok) {
+            int img, oy, ox;
+            decode_m(a, m, img, oy, ox);
+            const int ry = (oy * a.Hr) / a.Ho, rx = (ox * a.Wr) / a.Wo;
+            res_pix = (size_t)(img * a.Hr + ry) * a.Wr + rx;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = c_base + mt * 16 + 4 * lq;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j];
+            if (a.out_f32) {
+                if (!m_ok || co >= a.Cout) continue;
+                float* o = reinterpret_cast<float*>(a.out) + (size_t)m * a.Cout;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (co + j < a.Cout) {
+                        float x = v[j];
+                        if (a.bias) x += a.bias[co + j];
+                        if (a.res_mode) x += bf16_to_f32(a.res[res_pix * a.Cout + co + j]);
+                        if (a.relu == 1) x = fmaxf(x, 0.f);
+                        else if (a.relu == 2) x = tanhf(x);
+                        o[co + j] = x;
+                    }
+                }
+            } else if (a.pool) {
+                if (a.bias && co < a.Cout) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += b[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = quad_max(v[j]);
+                    if (a.relu == 1) x = fmaxf(x, 0.f);
+                    v[j] = x;
+                }
+                if (m_ok && co < a.Cout && (lane & 3) == 0) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)(m >> 2) * a.Cout + co) = o;
+                }
+            } else {
+                if (!m_ok || co >= a.Cout) continue;
+                if (a.bias) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += b[j];
+                }
+                if (a.res_mode) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + res_pix * a.Cout + co);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r[j]);
+                }
+                if (a.relu == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
             }
         }
     }
@@ -499,7 +578,14 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
 #define CVPCE_MFMAS(SLOT)                                                                                      \
     {                                                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                         \
-        if (!(CVPCE_DBG & 8)) {                                                                                \
+        if ((CVPCE_DBG & 32)) {                                                                                \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                \
+                f32x4* q4 = reinterpret_cast<f32x4*>(&acc[mt][nt]);                                            \
+                q4[2 * (SLOT)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SLOT][mt], bfr[SLOT][nt], q4[2 * (SLOT)], 0, 0, 0); \
+                q4[2 * (SLOT) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SLOT][mt], bfr[SLOT][nt], q4[2 * (SLOT) + 1], 0, 0, 0); \
+            }                                                                                                  \
+        } else if (!(CVPCE_DBG & 8)) {                                                                         \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SLOT][mt], bfr[SLOT][nt], acc[mt][nt], 0, 0, 0); \
@@ -540,6 +626,207 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
 #undef CVPCE_MFMAS
 #undef CVPCE_DMA4_STAGE
     conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+}
+
+// ===========================================================================
+// LDS-DMA kernel, 4-stage ring, v_mfma_f32_16x16x32_bf16 variant
+// ===========================================================================
+// Same staging / ring / hand-off as conv_dma4_kernel, but the products run on the 16x16x32 MFMA shape: at equal
+// cycles per FLOP the chip holds a higher clock on it under load (measured here: MFMA-only stream of VGG conv4_2
+// 0.99 -> 0.89 ms, whole kernel +7 %; cf. MI355X_MICROARCH.md DVFS item 7).  A lane's fragment is row (lane&15),
+// 16-byte K-chunk (lane>>4) of a 16-row block, so one ds_read_b128 covers a whole 16x32 operand block; the XOR term
+// T[(row>>2)&3], T = {0,2,3,1}, keeps those reads conflict-free.  Accumulators: col = lane&15 (pixel),
+// row = 4*(lane>>4)+reg (cout).
+// Issued -> landed latency of an LDS-DMA piece under load is ~1 us (about one 64-deep K-step of
+// MFMA time), so a 2-buffer scheme exposes it every step.  Here the ring holds four 32-deep
+// K-steps (4 x 32 KiB at 256x256): stage t+3 is issued while stage t computes, the wave waits with
+// a COUNTED vmcnt (never 0 in steady state) and a raw s_barrier (a __syncthreads() would drain
+// vmcnt to 0).  K order: (64-channel chunk, kh, kw, 32-channel half, channel).
+template <int TC, int TP, int WC, int WP, int MINW, int NS>
+__global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs a) {
+    constexpr int BK = 32;
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    constexpr int NW = WC * WP;
+    constexpr int WJ = TC / (16 * NW);     // weight DMA pieces per wave per K-step (16 rows of 64 B each)
+    constexpr int PJ = TP / (16 * NW);
+    constexpr int NP = WJ + PJ;
+    constexpr int MT = TC / WC / 16;      // 16-row cout blocks per wave
+    constexpr int NT = TP / WP / 16;      // 16-pixel blocks per wave
+    static_assert(MT % 2 == 0, "cout blocks split in two pipeline groups");
+    static_assert(WJ >= 1 && PJ >= 1, "tile/wave geometry");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);          // [NS][TC][BK]
+    bf16_t* Ps = Ws + NS * TC * BK;                        // [NS][TP][BK]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid / WP, wp = wid % WP;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = swz % a.tiles_c, tile_p = swz / a.tiles_c;
+
+    // piece j of wave w fills rows j*16*NW + w*16 .. +15 (row = lane>>2, physical chunk = lane&3);
+    // swizzle T[(row>>2)&3] = T[(lane>>4)&3] is the same for every piece of a lane
+    const int lrow = wid * 16 + (lane >> 2);
+    const int lchunk = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);   // T = {0,2,3,1} packed in 0x78
+
+    // Per-lane, K-invariant part of every pixel-piece address, computed ONCE: byte offset of (image, oy*stride,
+    // ox*stride, lane's 8-channel slice) and a bit mask of the taps that fall inside the image.  The tap / channel
+    // walk of the K loop is wave-uniform (SALU); each DMA piece then costs one v_add + one v_cndmask of address math.
+    // (Ablation, VGG conv4_2: with the per-piece index recomputation the DMA stage cost 0.31 ms of a 1.37 ms launch.)
+    unsigned poff[PJ], pmask[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int m = tile_p * TP + j * 16 * NW + lrow;
+        poff[j] = 0u;
+        pmask[j] = 0u;
+        if (m < a.M) {
+            int img, oy, ox;
+            decode_m(a, m, img, oy, ox);
+            const int y0 = oy * a.stride, x0 = ox * a.stride;
+            poff[j] = (unsigned)((((size_t)(img * a.H + y0) * a.W + x0) * a.Cin + lchunk * 8) * 2);
+            for (int t = 0; t < a.KH * a.KW; ++t) {
+                const int iy = y0 - a.pad + t / a.KW, ix = x0 - a.pad + t % a.KW;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) pmask[j] |= 1u << t;
+            }
+        }
+    }
+    // wave-uniform K walk: (64-channel chunk, kh, kw, 32-channel half)
+    int kh = 0, kw = 0, half = 0, cbase = 0, tapi = 0;
+    int tap_off = ((0 - a.pad) * a.W + (0 - a.pad)) * a.Cin * 2;     // byte shift of tap (kh,kw), may be negative
+
+    // LDS-DMA through BUFFER instructions (`buffer_load_dwordx4 ... offen lds`), not `global_load_lds`: the latter is
+    // FLAT-encoded, and hipcc then treats every later LDS wait as lgkmcnt(0) (flat ops may return out of order), which
+    // serialises the fragment prefetch.  A buffer descriptor also gives the zero fill for free: an out-of-range
+    // offset (padding halo, ragged rows, K padding) returns 0 -- no zero page, no select on a 64-bit pointer.
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    unsigned woff[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+        woff[j] = (unsigned)(((size_t)(tile_c * TC + lrow + j * 16 * NW) * a.K_pad + lchunk * 8) * 2);
+#define CVPCE_DMA4_STAGE(KT, BUF)                                                                              \
+    {                                                                                                          \
+        const int kbyte = (KT) * (BK * 2);                                                                     \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j)                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w,                                                    \
+                (lds_void*)(Ws + (BUF) * TC * BK + (j * 16 * NW + wid * 16) * BK), 16, (int)woff[j], kbyte, 0, 0); \
+        const int uni = tap_off + (cbase + 32 * half) * 2;                                                     \
+        const bool ch_ok = cbase < a.Cin;                                                                      \
+        _Pragma("unroll") for (int j = 0; j < PJ; ++j) {                                                       \
+            const bool ok = ch_ok && ((pmask[j] >> tapi) & 1u);                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p,                              \
+                (lds_void*)(Ps + (BUF) * TP * BK + (j * 16 * NW + wid * 16) * BK), 16,                         \
+                (int)(ok ? poff[j] + (unsigned)uni : 0xFFFFFFF0u), 0, 0, 0);                                   \
+        }                                                                                                      \
+        half ^= 1;                                                                                             \
+        if (half == 0) {                                                                                       \
+            ++tapi;                                                                                            \
+            tap_off += a.Cin * 2;                                                                              \
+            if (++kw == a.KW) {                                                                                \
+                kw = 0;                                                                                        \
+                tap_off += (a.W - a.KW) * a.Cin * 2;                                                           \
+                if (++kh == a.KH) {                                                                            \
+                    kh = 0; tapi = 0; cbase += 64;                                                             \
+                    tap_off = ((0 - a.pad) * a.W + (0 - a.pad)) * a.Cin * 2;                                   \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = a.K_pad / BK;
+    // Software pipeline over 16-deep fragment groups (two per stage).  The ds_reads of group g+1 are issued
+    // BEFORE the MFMAs of group g and the stage hand-off (counted vmcnt + barrier + next DMA issue) sits between the
+    // two MFMA groups of a stage, so the matrix pipe keeps draining 8 queued MFMAs while the wave waits, syncs and
+    // issues DMA.  (Ablation on VGG conv4_2: fragment reads + barrier with neither DMA nor MFMA took 0.72 ms of a
+    // 1.43 ms launch when they were serialised with the MFMAs.)
+    //   stage s lives in ring slot s & 3; when MFMA(kt, group 1) is issued, stage kt+1 must be visible (its group-0
+    //   fragments are being fetched) and stages kt+2, kt+3 are in flight.
+    CVPCE_DMA4_STAGE(0, 0)
+    if (nk > 1) CVPCE_DMA4_STAGE(1, 1)
+    if (NS == 4 && nk > 2) CVPCE_DMA4_STAGE(2, 2)
+    // Fragment pipeline.  Group 0 = cout blocks 0..MT/2-1 + ALL pixel blocks (MT/2 + NT reads), group 1 = cout blocks
+    // MT/2..MT-1 (MT/2 reads).  Pixel fragments are double buffered across stages (group 1 of stage t still multiplies
+    // stage t's pixels while group 0 of stage t+1 is being fetched).
+    constexpr int MH = MT / 2;
+    const unsigned lds_w0 = (unsigned)(size_t)(lds_char*)Ws, lds_p0 = (unsigned)(size_t)(lds_char*)Ps;
+    const unsigned lrow16 = lane & 15;
+    const unsigned lane_off = lrow16 * (BK * 2) + (((lane >> 4) ^ ((0x78 >> (2 * (lrow16 >> 2))) & 3)) << 4);
+    const unsigned wlane = lds_w0 + wc * (TC / WC) * (BK * 2) + lane_off;
+    const unsigned plane = lds_p0 + wp * (TP / WP) * (BK * 2) + lane_off;
+    bf16x8 af[MT], bfr[2][NT];
+#define CVPCE_READ_A(STAGE, M0)                                                                                \
+    {                                                                                                          \
+        const unsigned wb_ = wlane + ((STAGE) % NS) * (TC * BK * 2);                                           \
+        _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                         \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[(M0) + i]) : "v"(wb_ + ((M0) + i) * 16 * (BK * 2)));  \
+    }
+#define CVPCE_READ_B(STAGE, SET)                                                                               \
+    {                                                                                                          \
+        const unsigned pb_ = plane + ((STAGE) % NS) * (TP * BK * 2);                                           \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                      \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[SET][nt]) : "v"(pb_ + nt * 16 * (BK * 2)));          \
+    }
+#define CVPCE_MFMAS(M0, SET)                                                                                   \
+    {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
+                acc[(M0) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(M0) + i], bfr[SET][nt], acc[(M0) + i][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    }
+    // stage 0 becomes visible; fetch its group 0
+    if (NS == 4 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    CVPCE_READ_A(0, 0)
+    CVPCE_READ_B(0, 0)
+    // the loop body is written for even/odd stages explicitly so that the pixel-fragment set index is a constant
+#define CVPCE_STAGE_BODY(KT, SET)                                                                              \
+    {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* group 0 of stage KT has landed */           \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        CVPCE_READ_A(KT, MH)                                    /* group 1, in flight under MFMA group 0 */    \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        CVPCE_MFMAS(0, SET)                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if ((KT) + 1 < nk) {                                                                                   \
+            const int ahead = nk - 2 - (KT);                                                                   \
+            if (NS == 4 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");               \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
+            __builtin_amdgcn_s_barrier();                                                                      \
+            if ((KT) + NS - 1 < nk) CVPCE_DMA4_STAGE((KT) + NS - 1, ((KT) + NS - 1) % NS)                      \
+            CVPCE_READ_A((KT) + 1, 0)                           /* group 0 of the next stage */                \
+            CVPCE_READ_B((KT) + 1, (SET) ^ 1)                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MH + NT) : "memory");   /* group 1 landed */            \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        CVPCE_MFMAS(MH, SET)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        CVPCE_STAGE_BODY(kt, 0)
+        CVPCE_STAGE_BODY(kt + 1, 1)
+    }
+    if (kt < nk) CVPCE_STAGE_BODY(kt, 0)
+#undef CVPCE_STAGE_BODY
+#undef CVPCE_READ_A
+#undef CVPCE_READ_B
+#undef CVPCE_MFMAS
+#undef CVPCE_DMA4_STAGE
+    conv_epilogue16<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
 // ===========================================================================
@@ -711,6 +998,24 @@ static int launch_conv_dma4(const ConvArgs& a0, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
+template <int TC, int TP, int WC, int WP, int MINW, int NS>
+static int launch_conv_dma16(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_p = (a.M + TP - 1) / TP;
+    a.tiles_c = (a.Cout + TC - 1) / TC;
+    const size_t smem = (size_t)NS * (TC + TP) * 32 * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_dma16_kernel<TC, TP, WC, WP, MINW, NS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_p * a.tiles_c);
+    hipLaunchKernelGGL((conv_dma16_kernel<TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
+    return cvpce_check_launch();
+}
+
 extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res,
                                       void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                       int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
@@ -747,7 +1052,8 @@ extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const flo
     if (bk64 && force_generic != 1) {
         if (Cout >= 192 && tiles256 * ((Cout + 255) / 256) >= 128)
             return (force_generic == 2 || in_up_shift || KH * KW > 32) ? launch_conv_dma<256, 256, 2, 4, 2>(a, s)
-                                                                        : launch_conv_dma4<256, 256, 2, 4, 2, 4>(a, s);
+                   : (force_generic == 3)                                ? launch_conv_dma4<256, 256, 2, 4, 2, 4>(a, s)
+                                                                        : launch_conv_dma16<256, 256, 2, 4, 2, 4>(a, s);
         if (Cout > 64 && Cout <= 128 && tiles256 >= 128) return launch_conv_dma<128, 128, 2, 2, 2>(a, s);
         if (Cout > 32 && Cout <= 64 && tiles256 >= 128) return launch_conv_dma<64, 128, 2, 2, 2>(a, s);
     }

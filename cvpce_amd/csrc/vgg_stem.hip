@@ -18,6 +18,12 @@
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 
+// compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 skip phase 1 (conv1_1),
+// 2 skip phase 2 MFMAs, 4 skip phase 2 fragment reads, 8 skip the output stores, 16 skip the input patch loads
+#ifndef CVPCE_DBG
+#define CVPCE_DBG 0
+#endif
+
 #define ST_T 16                    // output tile edge
 #define ST_P1 (ST_T + 2)           // conv1_1 patch edge (halo 1)
 #define ST_P0 (ST_T + 4)           // input patch edge (halo 2)
@@ -122,16 +128,24 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
             bias2[ct][g] = *reinterpret_cast<const f32x4*>(a.b2 + ct * 32 + 8 * g + 4 * lh);
         }
 
+    // conv1_1's A operand (64 couts x 48 k) is tiny: keep this lane's 6 fragments in registers for the whole kernel
+    bf16x8 w1frag[3][2];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+            w1frag[kh][ct] = *reinterpret_cast<const bf16x8*>(W1 + (ct * 32 + lr) * 96 + kh * 32 + lh * 16);
+
     for (; tile < a.ntiles; tile += gridDim.x) {
         const int n = tile / (a.tiles_x * a.tiles_y);
         const int rem = tile - n * (a.tiles_x * a.tiles_y);
         const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
         const int next = tile + gridDim.x;
-        if (next < a.ntiles) load_patch(next);          // global loads in flight under both MFMA phases
+        if (next < a.ntiles && !(CVPCE_DBG & 16)) load_patch(next);          // global loads in flight under both MFMA phases
 
         // ================= phase 1: conv1_1 on the 18x18 patch -> A1 =================
         const unsigned char* INb = IN + buf * ST_IN_BYTES;
-        for (int pt = wid; pt < ST_ROWS1 / 32; pt += 4) {
+        for (int pt = wid; pt < ((CVPCE_DBG & 1) ? 0 : ST_ROWS1 / 32); pt += 4) {
             int pp = pt * 32 + lr;
             const bool real = pp < ST_NPIX1;
             if (!real) pp = ST_NPIX1 - 1;
@@ -141,19 +155,20 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+            // B fragments: k = kh*16 + 8h + j  <->  pixels (py+kh, px+2h .. px+2h+1), 4 channels each: 16 contiguous bytes.
+            // All three are fetched before the MFMAs; the A fragments (conv1_1 weights) never leave registers.
+            union { unsigned long long u[2]; bf16x8 v; } bfrag[3];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                // B fragment: k = kh*16 + 8h + j  <->  pixels (py+kh, px+2h .. px+2h+1), 4 channels each: 16 contiguous bytes
                 const unsigned char* src = INb + ((py + kh) * ST_P0 + px + 2 * lh) * 8;
-                union { unsigned long long u[2]; bf16x8 v; } bfrag;
-                bfrag.u[0] = *reinterpret_cast<const unsigned long long*>(src);
-                bfrag.u[1] = *reinterpret_cast<const unsigned long long*>(src + 8);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(W1 + (ct * 32 + lr) * 96 + kh * 32 + lh * 16);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag.v, acc[ct], 0, 0, 0);
-                }
+                bfrag[kh].u[0] = *reinterpret_cast<const unsigned long long*>(src);
+                bfrag[kh].u[1] = *reinterpret_cast<const unsigned long long*>(src + 8);
             }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1frag[kh][ct], bfrag[kh].v, acc[ct], 0, 0, 0);
             // epilogue: bias + ReLU, zero outside the image (conv1_2 pads conv1_1's OUTPUT with zeros)
             const int y = ty * ST_T - 1 + py, x = tx * ST_T - 1 + px;
             const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
@@ -201,38 +216,50 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
         ST_LOAD(1, 1)
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (s + 2 < 36) ST_LOAD(s + 2, (s + 2) % 3)
+            if (s + 2 < 36 && !(CVPCE_DBG & 4)) ST_LOAD(s + 2, (s + 2) % 3)
             __builtin_amdgcn_sched_barrier(0);
+            if (!(CVPCE_DBG & 2)) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % 3][mt], bfr[s % 3][nt], acc[mt][nt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef ST_LOAD
-        // epilogue: bias, 2x2 max over the quad's 4 lanes, ReLU, store the pooled pixel
+        // epilogue: bias, 2x2 max over the quad's 4 lanes (DPP), ReLU.  After pooling the 4 lanes of a quad hold the
+        // same 64 values; lane `sub` keeps channel group g = sub, then a v_permlane32_swap pair gives every lane
+        // 8 consecutive channels: ONE 16-byte store per lane per pixel tile, all 64 lanes active.
         const int Ho = a.H >> 1, Wo = a.W >> 1;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int oyp = (ty * ST_T) / 2 + (2 * wid + nt), oxp = (tx * ST_T) / 2 + q;
-            bf16_t* orow = a.out + ((size_t)(n * Ho + oyp) * Wo + oxp) * 64;
+            unsigned pk[2][2];     // [mt][dword]: this lane's 4 channels (8 sub + 4 lh ..+3) of cout tile mt, bf16x2 packed
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt) {
+                bf16x4 sel;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sel[j] = (bf16_t)0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = mt * 32 + 8 * g + 4 * lh;
                     const f32x4 b = bias2[mt][g];
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x = acc[mt][nt][4 * g + j] + b[j];
-                        x = fmaxf(x, __shfl_xor(x, 1));
-                        x = fmaxf(x, __shfl_xor(x, 2));
-                        o[j] = f32_to_bf16(fmaxf(x, 0.f));
-                    }
-                    if (sub == 0) *reinterpret_cast<bf16x4*>(orow + co) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(fmaxf(quad_max(acc[mt][nt][4 * g + j] + b[j]), 0.f));
+                    if (sub == g) sel = o;
                 }
+                const uint2 u = *reinterpret_cast<const uint2*>(&sel);
+                pk[mt][0] = u.x; pk[mt][1] = u.y;
+            }
+            // lanes 0-31 (lh = 0) end with cout tile 0, channels 8 sub .. 8 sub + 7; lanes 32-63 with cout tile 1
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                pk[0][d] = r[0]; pk[1][d] = r[1];
+            }
+            const int oyp = (ty * ST_T) / 2 + (2 * wid + nt), oxp = (tx * ST_T) / 2 + q;
+            bf16_t* dst = a.out + ((size_t)(n * Ho + oyp) * Wo + oxp) * 64 + lh * 32 + sub * 8;
+            if (!(CVPCE_DBG & 8)) *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
         }
         if (next < a.ntiles) store_patch(buf ^ 1);
         __syncthreads();      // A1 is free again; the next input patch is visible

@@ -85,7 +85,7 @@ class ConvProfile:
         tiles256 = (m + 255) // 256
         if bk64 and not FORCE_GENERIC_CONV:
             if pc.cout >= 192 and tiles256 * ((pc.cout + 255) // 256) >= 128:
-                return 'conv_dma4_kernel<256,256,2,4,2,4>'
+                return 'conv_dma16_kernel<256,256,2,4,2,4>'
             if 64 < pc.cout <= 128 and tiles256 >= 128:
                 return 'conv_dma_kernel<128,128,2,2,2>'
             if 32 < pc.cout <= 64 and tiles256 >= 128:

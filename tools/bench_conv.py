@@ -25,10 +25,21 @@ ap.add_argument('--layers', default=','.join(LAYERS))
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--generic', type=int, default=0)
 ap.add_argument('--dbg', type=int, default=0)
+ap.add_argument('--stem', action='store_true', help='time the fused VGG stem kernel on 256 crops')
 args = ap.parse_args()
 dev = torch.device('cuda')
 ops.FORCE_GENERIC_CONV = args.generic
 
+if args.stem:
+    g = torch.Generator().manual_seed(0)
+    ps = ops.PackedStem(torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5, torch.zeros(64), torch.randn(64, 64, 3, 3, generator=g) / 24.0, torch.zeros(64), device=dev)
+    x = torch.zeros(256, 256, 256, 8, dtype=torch.bfloat16); x[..., :3] = torch.randn(256, 256, 256, 3, generator=g).to(torch.bfloat16); x = x.to(dev)
+    for _ in range(2): y = ops.vgg_stem(x, ps)
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
+    for _ in range(args.iters): y = ops.vgg_stem(x, ps)
+    e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / args.iters
+    print(f'vgg_stem 256 crops {ms:8.3f} ms  {ps.flops_per_pixel * 256 * 65536 / ms / 1e9:8.1f} TFLOP/s')
+    sys.exit(0)
 for name in args.layers.split(','):
     n, cin, h, w, cout, k, stride, pad, pool = LAYERS[name]
     g = torch.Generator().manual_seed(0)
