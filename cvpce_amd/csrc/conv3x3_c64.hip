@@ -1,0 +1,207 @@
+// 3x3 stride-1 pad-1 convolution with Cin = 64 and ALL of its weights resident in LDS (VGG16 conv2_1, 64 -> 128
+// at 128x128: 9 K-steps per tile in the implicit-GEMM kernels, where the per-tile prologue and the weight re-staging
+// dominate).  Persistent workgroups; workgroup b owns the 64-channel output group b % (Cout/64) for its whole life:
+//   * its 9 x 64 x 64 weight slab (72 KiB) is loaded into LDS once,
+//   * per 16x16 output tile the 18x18x64 input halo patch (40.5 KiB) is fetched by LDS-DMA
+//     (`buffer_load_dwordx4 ... lds`, descriptor range check = zero padding), double buffered: the patch of
+//     tile t+1 lands while tile t computes,
+//   * the 9 taps x 4 K-steps run out of LDS with no barrier inside (fragments two K-steps ahead in registers),
+//   * bias + ReLU, 16-byte stores after a v_permlane32_swap pair.
+// Same numerics as cvpce_conv2d_nhwc_bf16 (bf16 operands, fp32 accumulate, bf16 output).
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+
+#define C6_T 16
+#define C6_P (C6_T + 2)              // 18
+#define C6_NPIX (C6_P * C6_P)        // 324
+#define C6_ROWS 328                  // 41 DMA pieces of 8 rows
+#define C6_W_BYTES (9 * 64 * 128)
+#define C6_A_BYTES (C6_ROWS * 128)
+#define C6_SMEM (C6_W_BYTES + 2 * C6_A_BYTES)
+#define C6_NPIECE (C6_ROWS / 8)      // 41
+
+struct C64Args {
+    const bf16_t* in;    // [N][H][W][64]
+    const bf16_t* wgt;   // [Cout_pad][576]  k = (kh*3 + kw)*64 + ci
+    const float* bias;   // [Cout] or null
+    bf16_t* out;         // [N][H][W][Cout]
+    int N, H, W, Cout, relu;
+    int tiles_x, tiles_y, ntiles, ngroups;
+    unsigned in_bytes;
+};
+
+__device__ __forceinline__ unsigned c6_off(int pp, int chunk) { return pp * 128 + ((chunk ^ ((pp >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C64Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Wl = smem;
+    unsigned char* A0 = Wl + C6_W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int group = blockIdx.x % a.ngroups;              // 64-channel output group of this workgroup
+    const int first = blockIdx.x / a.ngroups, stride = gridDim.x / a.ngroups;
+
+    // resident weights: rows (tap*64 + co) of 128 B, XOR-swizzled
+    for (int i = tid; i < 9 * 64 * 8; i += 256) {
+        const int row = i >> 3, ch = i & 7, tap = row >> 6, co = row & 63;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(a.wgt + (size_t)(group * 64 + co) * 576 + tap * 64 + ch * 8);
+        *reinterpret_cast<u32x4*>(Wl + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+
+    // patch DMA: piece j covers patch rows 8j..8j+7; lane -> row 8j + (lane>>3), physical chunk lane&7
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const unsigned lds_a0 = (unsigned)(size_t)(lds_char*)A0;
+    auto issue_patch = [&](int tile, int buf) {
+        const int n = tile / (a.tiles_x * a.tiles_y);
+        const int r = tile - n * (a.tiles_x * a.tiles_y);
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        for (int j = wid; j < C6_NPIECE; j += 4) {
+            const int pp = j * 8 + (lane >> 3);
+            const int py = pp / C6_P, px = pp - py * C6_P;
+            const int y = ty * C6_T - 1 + py, x = tx * C6_T - 1 + px;
+            const int lchunk = (lane & 7) ^ ((pp >> 1) & 7);
+            const bool ok = pp < C6_NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = (unsigned)((((size_t)(n * a.H + y) * a.W + x) * 64 + lchunk * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_void*)(A0 + buf * C6_A_BYTES + j * 1024), 16,
+                                                     (int)(ok ? off : 0xFFFFFFF0u), 0, 0, 0);
+        }
+    };
+
+    int tile = first;
+    int buf = 0;
+    if (tile < a.ntiles) issue_patch(tile, 0);
+
+    // lane constants: wave w owns output rows 4w..4w+3 = pixel tiles 2w, 2w+1 (32 px = 2 rows x 16 columns, row-major)
+    int pp2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) pp2[nt] = (2 * (2 * wid + nt) + (lr >> 4)) * C6_P + (lr & 15);
+    f32x4 bias[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias[mt][g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + group * 64 + mt * 32 + 8 * g + 4 * lh)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds_w = (unsigned)(size_t)(lds_char*)Wl;
+
+    for (; tile < a.ntiles; tile += stride) {
+        const int n = tile / (a.tiles_x * a.tiles_y);
+        const int rem = tile - n * (a.tiles_x * a.tiles_y);
+        const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        // this tile's patch (and, first time round, the weights) must be in LDS for every wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int next = tile + stride;
+        if (next < a.ntiles) issue_patch(next, buf ^ 1);      // lands under this tile's 144 MFMAs per wave
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const unsigned abase = lds_a0 + buf * C6_A_BYTES;
+        bf16x8 af[3][2], bfr[3][2];
+#define C6_LOAD(S, SLOT)                                                                                       \
+        {                                                                                                      \
+            const int tap = (S) >> 2, kk = (S) & 3;                                                            \
+            const int kh = tap / 3, kw = tap - kh * 3;                                                         \
+            const int chunk = kk * 2 + lh;                                                                     \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                 \
+                const int row = tap * 64 + mt * 32 + lr;                                                       \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[SLOT][mt])                                        \
+                             : "v"(lds_w + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));                    \
+            }                                                                                                  \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[SLOT][nt])                                       \
+                             : "v"(abase + c6_off(pp2[nt] + kh * C6_P + kw, chunk)));                          \
+        }
+        C6_LOAD(0, 0)
+        C6_LOAD(1, 1)
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 2 < 36) {
+                C6_LOAD(s + 2, (s + 2) % 3)
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // K-step s landed; s+1, s+2 (4 reads each) in flight
+            } else if (s + 1 < 36) {
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % 3][mt], bfr[s % 3][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef C6_LOAD
+        // epilogue: bias + ReLU; lane (pixel lr, half lh) holds channels 8g + 4lh + {0..3} of each 32-channel block.
+        // Swapping piece g (kept by lanes 0-31) with piece g+2 (kept by lanes 32-63) across the two halves gives
+        // every lane 16 consecutive channels per block: two 16-byte stores.
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int oy = ty * C6_T + 2 * (2 * wid + nt) + (lr >> 4), ox = tx * C6_T + (lr & 15);
+            bf16_t* orow = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + group * 64;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = acc[mt][nt][4 * g + j] + bias[mt][g][j];
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        o[j] = f32_to_bf16(x);
+                    }
+                    const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                    pk[g][0] = u.x; pk[g][1] = u.y;
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        auto r = __builtin_amdgcn_permlane32_swap(pk[g][d], pk[g + 2][d], false, false);
+                        pk[g][d] = r[0]; pk[g + 2][d] = r[1];
+                    }
+                // lanes 0-31: (pk[g], pk[g+2]) = channels 8g .. 8g+7 for g = 0,1 ; lanes 32-63: channels 8(g+2) .. +7
+                bf16_t* dst = orow + mt * 32 + lh * 16;
+                *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[2][0], pk[2][1]};
+                *reinterpret_cast<u32x4*>(dst + 8) = u32x4{pk[1][0], pk[1][1], pk[3][0], pk[3][1]};
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+extern "C" int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bias, void* out, int N, int H,
+                                          int W, int Cout, int K_pad, int relu, void* stream) {
+    if (N <= 0) return CVPCE_OK;
+    if (!in || !wgt || !out) return CVPCE_ERR_ARG;
+    if (H % C6_T != 0 || W % C6_T != 0 || Cout % 64 != 0 || Cout <= 0 || Cout > 256 || K_pad != 576) return CVPCE_ERR_ARG;
+    if ((long long)N * H * W * 64 * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
+    C64Args a;
+    a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.out = (bf16_t*)out;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+    a.tiles_x = W / C6_T; a.tiles_y = H / C6_T; a.ntiles = N * a.tiles_x * a.tiles_y; a.ngroups = Cout / 64;
+    a.in_bytes = (unsigned)((long long)N * H * W * 64 * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C6_SMEM) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    int grid = 256 / a.ngroups * a.ngroups;                  // one persistent workgroup per CU, a whole number of groups
+    const long long want = (long long)a.ntiles * a.ngroups;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), C6_SMEM, (hipStream_t)stream, a);
+    return cvpce_check_launch();
+}

@@ -107,6 +107,7 @@ class ConvProfile:
 PROFILE = None   # set to a ConvProfile() to record
 
 
+USE_RESIDENT_C64 = True      # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel
 FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
 
 
@@ -126,10 +127,22 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         hr, wr = residual.shape[1], residual.shape[2]
         if res_mode == 0:
             res_mode = 1 if (hr, wr) == (ho, wo) else 2
+    resident = (USE_RESIDENT_C64 and not FORCE_GENERIC_CONV and pc.cin_pad == 64 and pc.kh == 3 and pc.kw == 3
+                and pc.stride == 1 and pc.pad == 1 and not pool and not out_f32 and residual is None and not in_up_shift
+                and act in (0, 1) and h % 16 == 0 and w % 16 == 0 and pc.cout % 64 == 0 and pc.cout <= 256
+                and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if resident:
+        rc = lib.cvpce_conv3x3_c64_resident(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, pc.cout, pc.k_pad,
+                                            int(act), _stream())
+        check(rc, 'cvpce_conv3x3_c64_resident')
+        if prof is not None:
+            e1.record()
+            prof.records.append(('conv3x3_c64_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+        return out
     rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
                                     pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),
                                     int(out_f32), int(in_up_shift), int(res_mode if residual is not None else 0),

@@ -52,6 +52,12 @@ int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, c
 int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
                          const float* b2, void* out, int N, int H, int W, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with Cin = 64 whose weights stay resident in LDS (VGG16 conv2_1): same
+ * operands, weight layout ([Cout_pad][576], k = (kh*3+kw)*64 + ci) and numerics as cvpce_conv2d_nhwc_bf16; H, W
+ * multiples of 16, Cout a multiple of 64 (<= 256); relu = 0/1.  out: [N][H][W][Cout] bf16. */
+int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                               int Cout, int K_pad, int relu, void* stream);
+
 /* nn.MaxPool2d (VGG 2x2 s2; ResNet stem 3x3 s2 p1), NHWC bf16 */
 int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
                               int Ho, int Wo, void* stream);

@@ -380,3 +380,26 @@ def test_vgg_stem_rejects_bad_shapes(cuda):
     ps = ops.PackedStem(torch.zeros(64, 3, 3, 3), torch.zeros(64), torch.zeros(64, 64, 3, 3), torch.zeros(64), device=cuda)
     with pytest.raises(RuntimeError):
         ops.vgg_stem(torch.zeros(1, 24, 16, 8, dtype=BF, device=cuda), ps)     # H not a multiple of 16
+
+
+@pytest.mark.parametrize('n,h,w,cout', [(4, 128, 128, 128), (9, 96, 112, 64), (5, 128, 128, 192)])
+def test_conv3x3_c64_resident_parity(cuda, n, h, w, cout):
+    """LDS-resident-weights kernel (VGG conv2_1 shape) against the oracle conv and bit-for-bit against the generic HIP kernel."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(cout + h)
+    x = r16(torch.randn(n, 64, h, w, generator=g))
+    wgt = torch.randn(cout, 64, 3, 3, generator=g) / 24.0
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
+    ref = F.relu(F.conv2d(x, r16(wgt), bias, padding=1))
+    xin = nhwc(x).to(cuda)
+    y = ops.conv2d(xin, pc, act=1)
+    assert rel_err(nchw(y), ref) < 1e-2
+    ops.USE_RESIDENT_C64 = False
+    try:
+        y2 = ops.conv2d(xin, pc, act=1)
+    finally:
+        ops.USE_RESIDENT_C64 = True
+    assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
+    y3 = ops.conv2d(xin, pc, act=0)       # no ReLU
+    assert rel_err(nchw(y3), F.conv2d(x, r16(wgt), bias, padding=1)) < 1e-2
