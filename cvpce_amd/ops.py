@@ -107,6 +107,7 @@ class ConvProfile:
 PROFILE = None   # set to a ConvProfile() to record
 
 
+USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
 USE_RESIDENT_C64 = True      # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel
 FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
 
@@ -131,10 +132,23 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
                 and pc.stride == 1 and pc.pad == 1 and not pool and not out_f32 and residual is None and not in_up_shift
                 and act in (0, 1) and h % 16 == 0 and w % 16 == 0 and pc.cout % 64 == 0 and pc.cout <= 256
                 and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
+    halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
+            and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
+            and act in (0, 1) and h % 16 == 0 and w % 16 == 0 and pc.cout % 4 == 0 and pc.cout > 64
+            and n * h * w >= 65536 and n * h * w * pc.cin_pad * 2 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if halo:
+        rc = lib.cvpce_conv3x3_halo(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
+                                    pc.cout_pad, int(act), int(pool), _stream())
+        check(rc, 'cvpce_conv3x3_halo')
+        if prof is not None:
+            e1.record()
+            prof.records.append((f'conv3x3_halo_kernel<{256 if pc.cout > 128 else 128}>',
+                                 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+        return out
     if resident:
         rc = lib.cvpce_conv3x3_c64_resident(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, pc.cout, pc.k_pad,
                                             int(act), _stream())

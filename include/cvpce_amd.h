@@ -58,6 +58,12 @@ int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, co
 int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
                                int Cout, int K_pad, int relu, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with Cin % 64 == 0 and the input halo patch resident in LDS (VGG16 conv2_2 ..
+ * conv5_3): same operands, weight layout and numerics as cvpce_conv2d_nhwc_bf16; H, W multiples of 16, Cout % 4 == 0;
+ * relu = 0/1; fuse_pool2 = 1 stores MaxPool2d(2,2) of the result ([N][H/2][W/2][Cout]). */
+int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                       int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+
 /* nn.MaxPool2d (VGG 2x2 s2; ResNet stem 3x3 s2 p1), NHWC bf16 */
 int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
                               int Ho, int Wo, void* stream);

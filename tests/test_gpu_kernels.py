@@ -403,3 +403,41 @@ def test_conv3x3_c64_resident_parity(cuda, n, h, w, cout):
     assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
     y3 = ops.conv2d(xin, pc, act=0)       # no ReLU
     assert rel_err(nchw(y3), F.conv2d(x, r16(wgt), bias, padding=1)) < 1e-2
+
+
+HALO_CASES = [  # n, cin, h, w, cout, pool
+    (4, 128, 128, 128, 128, True),     # VGG conv2_2 shape (TC = 128, pooled)
+    (16, 128, 64, 64, 256, False),     # conv3_1
+    (16, 256, 64, 64, 256, True),      # conv3_3 (pooled)
+    (64, 256, 32, 32, 512, False),     # conv4_1: two cout tiles
+    (256, 512, 16, 16, 512, False),    # conv5_x: one pixel tile per image
+    (5, 64, 112, 96, 192, False),      # ragged: Cout not a multiple of the cout tile, odd tile counts
+]
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,pool', HALO_CASES)
+def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool):
+    """Halo-patch kernel against the implicit-GEMM HIP kernel on the same inputs (and, for the small cases, the oracle)."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, h, w, cin, generator=g).to(BF)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
+    xin = x.to(cuda)
+    ops.USE_RESIDENT_C64 = False
+    try:
+        y = ops.conv2d(xin, pc, act=1, pool=pool)
+        ops.USE_HALO_3X3 = False
+        y2 = ops.conv2d(xin, pc, act=1, pool=pool)
+    finally:
+        ops.USE_HALO_3X3 = True
+        ops.USE_RESIDENT_C64 = True
+    torch.cuda.synchronize()
+    assert y.shape == y2.shape
+    assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
+    if n * h * w * cin * cout <= 4 * 128 * 128 * 128 * 128:
+        ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), r16(wgt), bias, padding=1))
+        if pool:
+            ref = F.max_pool2d(ref, 2, 2)
+        assert rel_err(nchw(y), ref) < 1e-2
