@@ -29,6 +29,7 @@ BBOX_XFORM_CLIP = math.log(1000.0 / 16)
 ANCHOR_SIZES = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in (32, 64, 128, 256, 512))
 ASPECT_RATIOS = (0.5, 1.0, 2.0)
 FPN_CHANNELS = 256
+N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
 
 
 # ---------------------------------------------------------------------------
@@ -255,6 +256,7 @@ class GLNEngine:
         self.reg_tower = [P(rh.conv[i]) for i in (0, 2, 4, 6)]
         self.reg_out = P(rh.bbox_reg)
         self.base_anchors = _base_anchors().to(device)
+        self.side_streams = [torch.cuda.Stream(device=device) for _ in range(4)] if N_SIDE_STREAMS else []
         self.num_anchors = self.base_anchors.shape[1]
         self.device = device
 
@@ -318,16 +320,40 @@ class GLNEngine:
         return ops.conv2d(x, self.g_subnet[4], act=2 if self.tanh else 1, out_f32=True)  # (N,H/2,W/2,1) f32
 
     def heads(self, feats):
-        cls, reg = [], []
-        for f in feats:
+        """cls / reg towers on the 5 pyramid levels: 10 independent conv chains.  The small levels (25x25 .. 7x7) launch
+        only a handful of workgroups each, so the chains are spread over side streams to run concurrently."""
+        n_levels = len(feats)
+        cls, reg = [None] * n_levels, [None] * n_levels
+
+        def chain(f, tower, final):
             t = f
-            for pc in self.cls_tower:
+            for pc in tower:
                 t = ops.conv2d(t, pc, act=1)
-            cls.append(ops.conv2d(t, self.cls_out, out_f32=True))
-            t = f
-            for pc in self.reg_tower:
-                t = ops.conv2d(t, pc, act=1)
-            reg.append(ops.conv2d(t, self.reg_out, out_f32=True))
+            return ops.conv2d(t, final, out_f32=True)
+
+        main = torch.cuda.current_stream()
+        if not self.side_streams:
+            for i, f in enumerate(feats):
+                cls[i] = chain(f, self.cls_tower, self.cls_out)
+                reg[i] = chain(f, self.reg_tower, self.reg_out)
+            return cls, reg
+        ready = torch.cuda.Event()
+        ready.record(main)
+        jobs = [(i, kind) for i in range(n_levels) for kind in ('cls', 'reg')]
+        done = []
+        for k, (i, kind) in enumerate(jobs):
+            stream = self.side_streams[k % len(self.side_streams)]
+            with torch.cuda.stream(stream):
+                stream.wait_event(ready)
+                out = chain(feats[i], self.cls_tower if kind == 'cls' else self.reg_tower,
+                            self.cls_out if kind == 'cls' else self.reg_out)
+                out.record_stream(main)          # consumed by the post-processing kernels on the main stream
+                (cls if kind == 'cls' else reg)[i] = out
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                done.append(ev)
+        for ev in done:
+            main.wait_event(ev)
         return cls, reg
 
     def postprocess(self, cls, reg, padded_hw, resized, original, num_classes, detections_per_img, conf_thresh):
