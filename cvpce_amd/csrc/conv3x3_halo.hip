@@ -36,9 +36,11 @@ struct HaloArgs {
     unsigned in_bytes, wgt_bytes;
 };
 
-template <int TC>
+// PAIR: the ring hand-off (vmcnt wait + barrier + DMA issue) happens every SECOND K-step and moves two K-slices at a
+// time (6 ring slots): with TC = 128 a K-step is only 16 MFMAs per wave, too little to amortise a barrier.
+template <int TC, bool PAIR>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(HaloArgs a) {
-    constexpr int BK = 32, NS = H3_NS;
+    constexpr int BK = 32, NS = PAIR ? 6 : H3_NS;
     constexpr int WC = 2, WP = 4;
     constexpr int MT = TC / WC / 16;          // 16-cout blocks per wave (8 or 4)
     constexpr int MH = MT / 2;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(HaloArgs a) {
     bf16x8 af[MT], bfr[2][NT];
 #define H3_READ_A(SLOTI, M0)                                                                                   \
     {                                                                                                          \
-        const unsigned wb_ = wlane + (unsigned)(SLOTI) * SLOT;                                                 \
+        const unsigned wb_ = wlane + (unsigned)(SLOTI) * SLOT;   /* SLOTI < NS */                                                 \
         _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                         \
             asm volatile("ds_read_b128 %0, %1" : "=v"(af[(M0) + i]) : "v"(wb_ + ((M0) + i) * 16 * (BK * 2)));  \
     }
@@ -183,47 +185,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(HaloArgs a) {
 
     // ---- prologue: patch of chunk 0, weights of stages 0..2 ----
     issue_patch(0, 0, 0);
-    issue_weights(0, 0, 0);
-    if (total_stages > 1) issue_weights(nst > 1 ? 0 : 1, nst > 1 ? 1 : 0, 1);
-    if (total_stages > 2) issue_weights(nst > 2 ? 0 : 1, nst > 2 ? 2 : 2 - nst, 2);
+    issue_weights(0, 0, 0);                                  // nst >= 18: the first K-steps all belong to tile 0
+    issue_weights(0, 1, 1);
+    issue_weights(0, 2, 2);
+    if (PAIR) issue_weights(0, 3, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     H3_READ_A(0, 0)
     H3_READ_B(0, 0, 0)
     // running position (all wave-uniform ints): g = flat K-step, r18 = K-step within the channel chunk, cc = flat chunk
     int g = 0, r18 = 0, cc = 0, cchunk = 0;      // cchunk = channel chunk within the current tile
+    int sl = 0;                                   // ring slot of K-step g (g % NS, kept incrementally)
+    auto slot_of = [&](int d) { int x = sl + d; return x >= NS ? x - NS : x; };     // slot of K-step g + d, d < NS
 
     // one K-step; SET = parity of g (pixel-fragment register set), kept a compile-time constant by the 2x unroll below
 #define H3_STAGE(SEQ, ST, SET)                                                                                 \
     {                                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* group 0 of this stage has landed */         \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        H3_READ_A(g & 3, MH)                                                                                   \
+        H3_READ_A(sl, MH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         H3_MFMAS(0, SET)                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (g + 1 < total_stages) {                                                                            \
-            /* hand-off: weights of stage g+1 (and a patch issued >= 1 stage ago) have landed; youngest allowed */ \
-            /* outstanding: weights of stage g+2 (WJ pieces) and, right after a patch issue, that patch           */ \
-            const bool patch_young = r18 == 1 && cc + 1 < total_chunks;                                        \
-            if (g + 2 < total_stages) {                                                                        \
-                if (patch_young) { if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + 6) : "memory"); \
-                                   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + 5) : "memory"); }        \
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");                                 \
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-            __builtin_amdgcn_s_barrier();                                                                      \
-            /* first K-step of a chunk: fetch the NEXT chunk's patch into the other buffer, BEFORE the weights */ \
-            if (r18 == 0 && cc + 1 < total_chunks) {                                                           \
-                const int nc_ = cchunk + 1;                                                                    \
-                if (nc_ < nchunks) issue_patch(0, nc_, (cc + 1) & 1); else issue_patch(1, 0, (cc + 1) & 1);    \
-            }                                                                                                  \
-            if (g + 3 < total_stages) {                                                                        \
-                if ((ST) + 3 < nst) issue_weights(0, (ST) + 3, (g + 3) & 3);                                   \
-                else issue_weights(1, (ST) + 3 - nst, (g + 3) & 3);                                            \
+            if (!PAIR) {                                                                                       \
+                /* hand-off: weights of stage g+1 (and a patch issued >= 1 stage ago) have landed; youngest allowed */ \
+                /* outstanding: weights of stage g+2 (WJ pieces) and, right after a patch issue, that patch       */ \
+                const bool patch_young = r18 == 1 && cc + 1 < total_chunks;                                    \
+                if (g + 2 < total_stages) {                                                                    \
+                    if (patch_young) { if (wid == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + 6) : "memory"); \
+                                       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ + 5) : "memory"); }    \
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WJ) : "memory");                             \
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+                __builtin_amdgcn_s_barrier();                                                                  \
+                /* first K-step of a chunk: fetch the NEXT chunk's patch into the other buffer, BEFORE the weights */ \
+                if (r18 == 0 && cc + 1 < total_chunks) {                                                       \
+                    const int nc_ = cchunk + 1;                                                                \
+                    if (nc_ < nchunks) issue_patch(0, nc_, (cc + 1) & 1); else issue_patch(1, 0, (cc + 1) & 1); \
+                }                                                                                              \
+                if (g + 3 < total_stages) {                                                                    \
+                    if ((ST) + 3 < nst) issue_weights(0, (ST) + 3, slot_of(3));                                \
+                    else issue_weights(1, (ST) + 3 - nst, slot_of(3));                                         \
+                }                                                                                              \
+            } else if ((SET) == 1) {                                                                           \
+                /* pair hand-off (odd K-step): K-steps g+1, g+2 were issued two steps ago and must have landed; */ \
+                /* the only younger DMA can be a patch issued right after them (at r18 == 1)                     */ \
+                const bool patch_young = r18 == 3 && cc + 1 < total_chunks;                                    \
+                if (patch_young) { if (wid == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              \
+                                   else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }                     \
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+                __builtin_amdgcn_s_barrier();                                                                  \
+                _Pragma("unroll") for (int d = 3; d <= 4; ++d)                                                 \
+                    if (g + d < total_stages) {                                                                \
+                        if ((ST) + d < nst) issue_weights(0, (ST) + d, slot_of(d));                            \
+                        else issue_weights(1, (ST) + d - nst, slot_of(d));                                     \
+                    }                                                                                          \
+                /* second K-step of a chunk: fetch the NEXT chunk's patch, AFTER the weights (it may stay in flight) */ \
+                if (r18 == 1 && cc + 1 < total_chunks) {                                                       \
+                    const int nc_ = cchunk + 1;                                                                \
+                    if (nc_ < nchunks) issue_patch(0, nc_, (cc + 1) & 1); else issue_patch(1, 0, (cc + 1) & 1); \
+                }                                                                                              \
             }                                                                                                  \
             const int nr18 = (r18 == 17) ? 0 : r18 + 1;                                                        \
             const int nbuf = (r18 == 17) ? ((cc + 1) & 1) : (cc & 1);                                          \
-            H3_READ_A((g + 1) & 3, 0)                                                                          \
+            H3_READ_A(slot_of(1), 0)                                                                           \
             H3_READ_B(nr18, nbuf, (SET) ^ 1)                                                                   \
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MH + NT) : "memory");                                   \
         } else {                                                                                               \
@@ -233,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(HaloArgs a) {
         H3_MFMAS(MH, SET)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         ++g;                                                                                                   \
+        if (++sl == NS) sl = 0;                                                                                \
         if (++r18 == 18) { r18 = 0; ++cc; ++cchunk; }                                                          \
     }
 
@@ -295,19 +321,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #undef H3_MFMAS
 }
 
-template <int TC>
+template <int TC, bool PAIR>
 static int launch_halo(HaloArgs a, hipStream_t stream) {
     a.ctiles = (a.Cout + TC - 1) / TC;
     a.ntiles = a.ptiles * a.ctiles;
-    const int smem = H3_NS * TC * 64 + 2 * H3_A_BYTES;
+    const int smem = (PAIR ? 6 : H3_NS) * TC * 64 + 2 * H3_A_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo_kernel<TC, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     const int grid = a.ntiles < 256 ? a.ntiles : 256;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<TC>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TC, PAIR>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
@@ -325,6 +351,6 @@ extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* 
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;
-    if (Cout > 128) return launch_halo<256>(a, (hipStream_t)stream);
-    return launch_halo<128>(a, (hipStream_t)stream);
+    if (Cout > 128) return launch_halo<256, false>(a, (hipStream_t)stream);
+    return launch_halo<128, true>(a, (hipStream_t)stream);
 }
