@@ -275,15 +275,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             size_t opix;
-            bool store_lane = true;
+            bool store_lane;                     // ragged right / bottom tiles: pixels outside the image are dropped
             if (a.pool) {
                 const int q = lp >> 2;
                 const int oy = (ty * H3_T) / 2 + 2 * wp + (nt >> 1), ox = (tx * H3_T) / 2 + 4 * (nt & 1) + q;
                 opix = (size_t)(n * (a.H >> 1) + oy) * (a.W >> 1) + ox;
-                store_lane = (lp & 3) == 0;
+                store_lane = (lp & 3) == 0 && oy < (a.H >> 1) && ox < (a.W >> 1);
             } else {
                 const int oy = ty * H3_T + 4 * wp + nt, ox = tx * H3_T + lp;
                 opix = (size_t)(n * a.H + oy) * a.W + ox;
+                store_lane = oy < a.H && ox < a.W;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -341,13 +342,14 @@ extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* 
                                   int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
-    if (H % H3_T != 0 || W % H3_T != 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 4 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
+    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 4 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
+    if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
     if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
     if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
     HaloArgs a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.out = (bf16_t*)out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu; a.pool = fuse_pool2 ? 1 : 0;
-    a.tiles_x = W / H3_T; a.tiles_y = H / H3_T; a.ptiles = N * a.tiles_x * a.tiles_y;
+    a.tiles_x = (W + H3_T - 1) / H3_T; a.tiles_y = (H + H3_T - 1) / H3_T; a.ptiles = N * a.tiles_x * a.tiles_y;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;

@@ -134,8 +134,9 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
                 and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
     halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
             and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
-            and act in (0, 1) and h % 16 == 0 and w % 16 == 0 and pc.cout % 4 == 0 and pc.cout > 64
-            and n * h * w >= 65536 and n * h * w * pc.cin_pad * 2 < 2 ** 32)
+            and act in (0, 1) and pc.cout % 4 == 0 and pc.cout > 64 and h % 16 == 0 and w % 16 == 0   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps)
+            and n * ((h + 15) // 16) * ((w + 15) // 16) * ((pc.cout + 255) // 256 if pc.cout > 128 else 1) >= 256
+            and n * h * w * pc.cin_pad * 2 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

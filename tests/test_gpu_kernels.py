@@ -412,6 +412,10 @@ HALO_CASES = [  # n, cin, h, w, cout, pool
     (64, 256, 32, 32, 512, False),     # conv4_1: two cout tiles
     (256, 512, 16, 16, 512, False),    # conv5_x: one pixel tile per image
     (5, 64, 112, 96, 192, False),      # ragged: Cout not a multiple of the cout tile, odd tile counts
+    (8, 256, 100, 100, 256, False),    # RetinaNet head on P3: H, W not multiples of the 16x16 tile
+    (8, 256, 50, 50, 256, False),      # ... on P4
+    (9, 128, 26, 38, 128, True),       # ragged + pooled (even sizes)
+    (8, 256, 13, 13, 256, False),      # smaller than one tile
 ]
 
 
