@@ -136,7 +136,7 @@ def main():
         # correction) and committed under profiles/; null if no profile covers the kernel
         traffic = None
         try:
-            prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01b_pmc_hbm_traffic.json')))
+            prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
             for k, v in prof.items():
                 if name.split('<')[0] in k and name.split('<')[1].split(',')[0] in k.split('<')[1]:
                     traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
