@@ -47,8 +47,13 @@ struct StemArgs {
     int tiles_x, tiles_y, ntiles;
 };
 
-__device__ __forceinline__ int a1_off(int pp, int chunk) {   // byte offset of 16-B chunk `chunk` of patch pixel pp
-    return pp * 128 + ((chunk ^ ((pp >> 1) & 7)) << 4);
+// byte offset of 16-B chunk `chunk` of conv1_1-output patch pixel (py, px).  The XOR makes the conv1_2 fragment reads
+// (ds_read_b128, served in the non-contiguous 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: four 2x2 quads whose
+// column pairs are distinct mod 4) conflict-free for every tap: bits 2:1 = column pair mod 4, bit 0 = row parity
+// (^ column pair bit 2).  See conv3x3_halo.hip h3_swz.
+__device__ __forceinline__ int a1_swz0(int u) { return ((u & 3) << 1) | ((u >> 2) & 1); }
+__device__ __forceinline__ int a1_off(int py, int px, int chunk) {
+    return (py * ST_P1 + px) * 128 + ((chunk ^ a1_swz0(px >> 1) ^ (py & 1)) << 4);
 }
 
 __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
@@ -110,11 +115,15 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
     // per-lane constants of the conv1_2 phase: wave w owns output rows 4w..4w+3 (pixel tiles 2w, 2w+1)
     // lane r of a 32-pixel tile: quad q = r>>2 -> columns 2q,2q+1 ; sub = r&3 -> row +(sub>>1), col +(sub&1)
     const int q = lr >> 2, sub = lr & 3;
-    int pp2[2];
+    // fragment address of (tap (kh,kw), K-step kk) = (rd2[nt][kw] ^ (((2 kk) ^ (kh & 1)) << 4)) + (kh*18 + kw) * 128:
+    // the per-lane part of the swizzle (K half lh, row parity, column pair of ox + kw) is folded into rd2 once
+    unsigned rd2[2][3];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int oy = 2 * (2 * wid + nt) + (sub >> 1), ox = 2 * q + (sub & 1);
-        pp2[nt] = oy * ST_P1 + ox;      // + kh*18 + kw per tap
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            rd2[nt][kw] = (unsigned)((oy * ST_P1 + ox) * 128 + ((lh ^ (oy & 1) ^ a1_swz0(((ox + kw) >> 1) & 7)) << 4));
     }
 
     // biases live in registers for the whole persistent loop (a global load per tile would put an
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
                         bf16x4 o;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(inside ? fmaxf(acc[ct][4 * g + j] + b[j], 0.f) : 0.f);
-                        *reinterpret_cast<bf16x4*>(A1 + a1_off(pp, co >> 3) + (co & 7) * 2) = o;
+                        *reinterpret_cast<bf16x4*>(A1 + a1_off(py, px, co >> 3) + (co & 7) * 2) = o;
                     }
             }
         }
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
                 af[SLOT][mt] = *reinterpret_cast<const bf16x8*>(W2 + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); \
             }                                                                                                  \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
-                bfr[SLOT][nt] = *reinterpret_cast<const bf16x8*>(A1 + a1_off(pp2[nt] + kh * ST_P1 + kw, chunk)); \
+                bfr[SLOT][nt] = *reinterpret_cast<const bf16x8*>(A1 + ((rd2[nt][kw] ^ (unsigned)(((2 * kk) ^ (kh & 1)) << 4)) + (unsigned)((kh * ST_P1 + kw) * 128))); \
         }
         // fragments run TWO K-steps ahead of the MFMAs (3 register slots); sched_barrier pins that order --
         // left alone, the scheduler sinks each ds_read group to just before its consumer and exposes the

@@ -107,6 +107,8 @@ class ConvProfile:
 PROFILE = None   # set to a ConvProfile() to record
 
 
+USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
+HALO_RAGGED = False          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
 USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
 USE_RESIDENT_C64 = True      # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel
 FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
@@ -134,16 +136,17 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
                 and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
     halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
             and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
-            and act in (0, 1) and pc.cout % 4 == 0 and pc.cout > 64 and h % 16 == 0 and w % 16 == 0   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps)
-            and n * ((h + 15) // 16) * ((w + 15) // 16) * ((pc.cout + 255) // 256 if pc.cout > 128 else 1) >= 256
+            and act in (0, 1) and pc.cout % 4 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0))   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps)
+            and (HALO_RAGGED or n * ((h + 15) // 16) * ((w + 15) // 16) * ((pc.cout + 255) // 256 if pc.cout > 128 else 1) >= 256)
             and n * h * w * pc.cin_pad * 2 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if halo:
-        rc = lib.cvpce_conv3x3_halo(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
-                                    pc.cout_pad, int(act), int(pool), _stream())
+        fn = lib.cvpce_conv3x3_halo_ring if USE_HALO_RING else lib.cvpce_conv3x3_halo
+        rc = fn(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
+                pc.cout_pad, int(act), int(pool), _stream())
         check(rc, 'cvpce_conv3x3_halo')
         if prof is not None:
             e1.record()

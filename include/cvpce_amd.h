@@ -64,6 +64,9 @@ int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bia
  * relu = 0/1; fuse_pool2 = 1 stores MaxPool2d(2,2) of the result ([N][H/2][W/2][Cout]). */
 int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                        int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+/* Same contract, first-generation kernel (weights through an LDS ring, one barrier per K-step); kept for A/B. */
+int cvpce_conv3x3_halo_ring(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                            int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
 
 /* nn.MaxPool2d (VGG 2x2 s2; ResNet stem 3x3 s2 p1), NHWC bf16 */
 int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,

@@ -419,9 +419,11 @@ HALO_CASES = [  # n, cin, h, w, cout, pool
 ]
 
 
+@pytest.mark.parametrize('ring', [False, True])
 @pytest.mark.parametrize('n,cin,h,w,cout,pool', HALO_CASES)
-def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool):
-    """Halo-patch kernel against the implicit-GEMM HIP kernel on the same inputs (and, for the small cases, the oracle)."""
+def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
+    """Halo-patch kernels (register-weights and LDS-ring generation) against the implicit-GEMM HIP kernel on the same
+    inputs (and, for the small cases, the oracle)."""
     from cvpce_amd import ops
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn(n, h, w, cin, generator=g).to(BF)
@@ -430,13 +432,20 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool):
     pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
     xin = x.to(cuda)
     ops.USE_RESIDENT_C64 = False
+    ops.HALO_RAGGED = True
+    ops.USE_HALO_RING = ring
+    ops.PROFILE = ops.ConvProfile()
     try:
         y = ops.conv2d(xin, pc, act=1, pool=pool)
+        assert [r[0] for r in ops.PROFILE.records][-1].startswith('conv3x3_halo')      # the halo path did run
         ops.USE_HALO_3X3 = False
         y2 = ops.conv2d(xin, pc, act=1, pool=pool)
     finally:
         ops.USE_HALO_3X3 = True
         ops.USE_RESIDENT_C64 = True
+        ops.HALO_RAGGED = False
+        ops.USE_HALO_RING = False
+        ops.PROFILE = None
     torch.cuda.synchronize()
     assert y.shape == y2.shape
     assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()

@@ -14,6 +14,7 @@ LAYERS = {
     'vgg3_2': (256, 256, 64, 64, 256, 3, 1, 1, False),
     'vgg4_1': (256, 256, 32, 32, 512, 3, 1, 1, False),
     'vgg4_2': (256, 512, 32, 32, 512, 3, 1, 1, False),
+    'vgg4_3': (256, 512, 32, 32, 512, 3, 1, 1, True),
     'vgg5_1': (256, 512, 16, 16, 512, 3, 1, 1, False),
     'res_c2_1x1': (8, 64, 200, 200, 256, 1, 1, 0, False),
     'res_c3_3x3': (8, 128, 100, 100, 128, 3, 1, 1, False),
@@ -27,12 +28,14 @@ ap.add_argument('--generic', type=int, default=0)
 ap.add_argument('--dbg', type=int, default=0)
 ap.add_argument('--no-resident', action='store_true')
 ap.add_argument('--no-halo', action='store_true')
+ap.add_argument('--ring', action='store_true')
 ap.add_argument('--stem', action='store_true', help='time the fused VGG stem kernel on 256 crops')
 args = ap.parse_args()
 dev = torch.device('cuda')
 ops.FORCE_GENERIC_CONV = args.generic
 ops.USE_RESIDENT_C64 = not args.no_resident
 ops.USE_HALO_3X3 = not args.no_halo
+ops.USE_HALO_RING = args.ring
 
 if args.stem:
     g = torch.Generator().manual_seed(0)
