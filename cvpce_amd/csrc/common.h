@@ -20,6 +20,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 
+// four floats -> four bf16 with two v_cvt_pk_bf16_f32 (element-wise casts compile to one conversion + a v_perm each)
+__device__ __forceinline__ bf16x4 f32x4_to_bf16x4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD
 // (round-robin dispatch), so give each XCD label a contiguous chunk of the
 // logical tile space -> neighbouring tiles hit the same per-XCD L2.  Speed
@@ -40,6 +43,18 @@ __device__ __forceinline__ float quad_max(float x) {
     x = fmaxf(x, y);
     y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));         // quad_perm [2,3,0,1]
     return fmaxf(x, y);
+}
+
+// ReLU on the bit pattern: negative floats are negative ints, so max_i32(bits, 0) is relu(x) in ONE v_max_i32 (under
+// IEEE mode fmaxf costs a canonicalising v_max x,x in front).  +NaN stays NaN, -NaN becomes 0, -0 becomes +0.
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// max over the 2x2 quad of NON-NEGATIVE floats (i.e. after relu_bits; relu(maxpool(x)) == maxpool(relu(x))): an integer
+// max, so each DPP move fuses into its v_max_i32 -- 2 VALU ops per value instead of 6
+__device__ __forceinline__ float quad_max_nonneg(float x) {
+    int v = __float_as_int(x);
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return __int_as_float(v);
 }
 
 static inline int cvpce_check_launch() {

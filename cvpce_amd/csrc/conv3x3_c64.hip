@@ -160,14 +160,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C64Args a) {
                 unsigned pk[4][2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    bf16x4 o;
+                    f32x4 r;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float x = acc[mt][nt][4 * g + j] + bias[mt][g][j];
-                        if (a.relu) x = fmaxf(x, 0.f);
-                        o[j] = f32_to_bf16(x);
+                        if (a.relu) x = relu_bits(x);
+                        r[j] = x;
                     }
-                    const uint2 u = *reinterpret_cast<const uint2*>(&o);
+                    const uint2 u = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r));
                     pk[g][0] = u.x; pk[g][1] = u.y;
                 }
 #pragma unroll

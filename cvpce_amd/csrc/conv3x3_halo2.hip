@@ -151,13 +151,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
     const unsigned lds_a = (unsigned)(size_t)(lds_char*)Ap;
 
+    // accumulators start from the bias of the tile's couts: the epilogue then needs no load (a bias load there sat,
+    // with its full L2 latency, between the last MFMA of a tile and its stores)
+    auto load_bias = [&](int ct, f32x4* b) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
+            b[mt] = (a.bias && co < a.Cout) ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     f32x4 acc[2][NB];
+    {
+        f32x4 b0[2];
+        load_bias(pi_ct, b0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < NB; ++j) acc[i][j] = b0[i];
+    }
 
     bf16x8 af[3][2][2];       // [tap % 3][K-half][16-cout block]
     bf16x8 bfr[8];            // pixel-fragment ring, slot = block & 7
@@ -274,6 +285,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         if (cchunk + 1 == nchunks) {
             // ---- epilogue of this tile (the next tile's patch, weights and first fragments are already in flight) ----
             const int n = t_n, ty = t_ty, tx = t_tx, ct = t_ct;
+            f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
+            load_bias(n_ct, nbias);
 #pragma unroll
             for (int nt = 0; nt < NB; ++nt) {
                 const int nb = wp * NB + nt;
@@ -295,29 +308,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j];
-                    if (a.bias && co < a.Cout) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
+                    if (a.relu) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += b[j];
-                    }
-                    if (POOL) {
+                        for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
+                        if (POOL) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = quad_max_nonneg(v[j]);
+                        }
+                    } else if (POOL) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = quad_max(v[j]);
                     }
-                    if (a.relu) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                    }
-                    if (store_lane && co < a.Cout) {
-                        bf16x4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
-                        *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = o;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mt][nt][e] = 0.f;
+                    if (store_lane && co < a.Cout)
+                        *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
                 }
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) acc[mt][nt] = nbias[mt];
             cchunk = 0;
             ++seq;
             if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct);

@@ -139,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     if (m_ok && co < a.Cout && (lane & 3) == 0) {
                         bf16x4 o;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                        for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
                         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)(m >> 2) * a.Cout + co) = o;
                     }
                 } else {
@@ -157,11 +157,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     }
                     if (a.relu == 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
                     }
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                    for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
                 }
             }
@@ -222,7 +222,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
                 if (m_ok && co < a.Cout && (lane & 3) == 0) {
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                    for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)(m >> 2) * a.Cout + co) = o;
                 }
             } else {
@@ -239,11 +239,11 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
                 }
                 if (a.relu == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
                 }
                 bf16x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(v[j]);
+                for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
             }
         }

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void vgg_stem_kernel(StemArgs a) {
     }
 }
 
-extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
+extern "C" int cvpce_vgg_stem_fused_1q(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
                                     const float* b2, void* out, int N, int H, int W, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in_nhwc || !w1 || !b1 || !w2 || !b2 || !out) return CVPCE_ERR_ARG;

@@ -1,0 +1,323 @@
+// Fused VGG16 stem for the MAC-VGG embedder (torchvision vgg cfg 'D' features[0:5]):
+//
+//     conv3x3(3->64)+bias+ReLU -> conv3x3(64->64)+bias+ReLU -> MaxPool2d(2,2)
+//
+// as ONE persistent kernel, second generation.  Same per-tile algorithm as vgg_stem.hip (conv1_1 on the 18x18 halo
+// patch into an LDS image, conv1_2's 36 K-steps out of LDS with resident weights, pooling in registers), but a
+// workgroup is now TWO independent 4-wave teams ("quads") that share the resident conv1_2 weights (72 KiB) and
+// own an LDS image + input staging buffer each.  One wave of each team sits on every SIMD, and the teams run out of
+// phase: while one is in its MFMA-bound conv1_2 phase the other does the VALU/LDS-bound parts (conv1_1 + its
+// epilogue, pooling, stores, input staging), which with one wave per SIMD (vgg_stem.hip) left the matrix pipe idle
+// for 40 % of every tile (profiles/r01d_ablation_stem.md).  The teams never wait for each other: team barriers are
+// LDS counters (ds_add + poll), s_barrier is used once, after the weights are resident.
+// Biases live in LDS and seed the accumulators (max(x + b) = max(x) + b), which also frees 64 VGPRs.
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+
+// compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 no initial de-phasing,
+// 2 raised priority in the conv1_2 phase, 4 NO raised priority outside it (the shipped default raises it: -8 %), 8 skip conv1_1, 16 skip the conv1_2 MFMAs
+#ifndef CVPCE_DBG
+#define CVPCE_DBG 0
+#endif
+
+#define S2_T 16                    // output tile edge
+#define S2_P1 (S2_T + 2)           // conv1_1 patch edge (halo 1)
+#define S2_P0 (S2_T + 4)           // input patch edge (halo 2)
+#define S2_NPIX1 (S2_P1 * S2_P1)   // 324
+#define S2_NPT 11                  // MFMA pixel tiles of 32 covering 324
+#define S2_W2_BYTES (9 * 64 * 128)
+#define S2_A1_BYTES (S2_NPIX1 * 128)
+#define S2_IN_BYTES (S2_P0 * S2_P0 * 8 + 64)   // + slack for the kw=3 over-read at the patch end
+#define S2_BIAS_BYTES 512
+#define S2_SMEM (S2_W2_BYTES + 2 * S2_A1_BYTES + 2 * S2_IN_BYTES + S2_BIAS_BYTES + 16)
+
+struct Stem2Args {
+    const bf16_t* in;    // [N][H][W][cstride] bf16, channels 0..2 used, channel 3 must be zero (cstride 4 or 8)
+    int cstride;
+    const bf16_t* w1;    // [64][48]  k = kh*16 + kw*4 + c
+    const float* b1;     // [64]
+    const bf16_t* w2;    // [9][64][64]  (tap, cout, cin)
+    const float* b2;     // [64]
+    bf16_t* out;         // [N][H/2][W/2][64]
+    int N, H, W;
+    int tiles_x, tiles_y, ntiles;
+};
+
+// byte offset of 16-B chunk `chunk` of conv1_1-output patch pixel (py, px): see vgg_stem.hip / conv3x3_halo2.hip
+__device__ __forceinline__ int s2_swz0(int u) { return ((u & 3) << 1) | ((u >> 2) & 1); }
+__device__ __forceinline__ int s2_a1_off(int py, int px, int chunk) {
+    return (py * S2_P1 + px) * 128 + ((chunk ^ s2_swz0(px >> 1) ^ (py & 1)) << 4);
+}
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+// barrier among the 4 waves of a team: arrive = ds_add on the team's LDS counter (after this wave's LDS traffic has
+// drained), wait = poll until all 4 arrivals of this round are in.  `target` counts arrivals expected so far.
+__device__ __forceinline__ void team_barrier(unsigned cnt_addr, unsigned& target, int lane) {
+    target += 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_addr), "v"(1u) : "memory");
+    for (;;) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_addr) : "memory");
+        if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* W2 = smem;
+    unsigned char* A1all = W2 + S2_W2_BYTES;
+    unsigned char* INall = A1all + 2 * S2_A1_BYTES;
+    float* BL = reinterpret_cast<float*>(INall + 2 * S2_IN_BYTES);     // [0..63] conv1_1 bias, [64..127] conv1_2 bias
+    unsigned* CNT = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(BL) + S2_BIAS_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wid8 >> 2, wid = wid8 & 3, qtid = tid & 255;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // ---- resident weights -> LDS (W2 rows of 128 B, XOR-swizzled like the GEMM tiles), biases, zeroed slack ----
+    for (int i = tid; i < 9 * 64 * 8; i += 512) {
+        const int row = i >> 3, ch = i & 7;           // row = tap*64 + cout
+        const u32x4 v = *reinterpret_cast<const u32x4*>(a.w2 + (size_t)row * 64 + ch * 8);
+        *reinterpret_cast<u32x4*>(W2 + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+    if (tid < 64) { BL[tid] = a.b1[tid]; BL[64 + tid] = a.b2[tid]; }
+    if (tid < 32) *reinterpret_cast<unsigned*>(INall + (tid >> 4) * S2_IN_BYTES + S2_P0 * S2_P0 * 8 + (tid & 15) * 4) = 0u;
+    if (tid < 2) CNT[tid] = 0u;
+    __syncthreads();
+
+    unsigned char* A1 = A1all + team * S2_A1_BYTES;
+    unsigned char* IN = INall + team * S2_IN_BYTES;
+    const unsigned cnt_addr = (unsigned)(size_t)(lds_char*)(CNT + team);
+    unsigned bar_target = 0;
+
+    // input patch staging: 400 pixels of 8 B, two per thread of the team (second one only for qtid < 144)
+    unsigned long long preg[2];
+    auto load_patch = [&](int tile) {
+        const int n = tile / (a.tiles_x * a.tiles_y);
+        const int r = tile - n * (a.tiles_x * a.tiles_y);
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = qtid + k * 256;
+            unsigned long long v = 0ull;
+            if (p < S2_P0 * S2_P0) {
+                const int py = p / S2_P0, px = p - py * S2_P0;
+                const int y = ty * S2_T - 2 + py, x = tx * S2_T - 2 + px;
+                if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                    v = *reinterpret_cast<const unsigned long long*>(a.in + ((size_t)(n * a.H + y) * a.W + x) * a.cstride);
+            }
+            preg[k] = v;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = qtid + k * 256;
+            if (p < S2_P0 * S2_P0) *reinterpret_cast<unsigned long long*>(IN + p * 8) = preg[k];
+        }
+    };
+
+    const int stride = 2 * (int)gridDim.x;
+    int tile = 2 * (int)blockIdx.x + team;
+    if (tile >= a.ntiles) return;                     // (team-uniform; the other team does not wait for this one)
+    load_patch(tile);
+    store_patch();
+    team_barrier(cnt_addr, bar_target, lane);
+
+    // per-lane constants of the conv1_2 phase: wave w owns output rows 4w..4w+3 (pixel tiles 2w, 2w+1)
+    // lane r of a 32-pixel tile: quad q = r>>2 -> columns 2q,2q+1 ; sub = r&3 -> row +(sub>>1), col +(sub&1)
+    const int q = lr >> 2, sub = lr & 3;
+    // fragment address of (tap (kh,kw), K-step kk) = (rd2[nt][kw] ^ (((2 kk) ^ (kh & 1)) << 4)) + (kh*18 + kw) * 128:
+    // the per-lane part of the swizzle (K half lh, row parity, column pair of ox + kw) is folded into rd2 once
+    unsigned rd2[2][3];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int oy = 2 * (2 * wid + nt) + (sub >> 1), ox = 2 * q + (sub & 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            rd2[nt][kw] = (unsigned)((oy * S2_P1 + ox) * 128 + ((lh ^ (oy & 1) ^ s2_swz0(((ox + kw) >> 1) & 7)) << 4));
+    }
+
+    // conv1_1's A operand (64 couts x 48 k) is tiny: keep this lane's 6 fragments in registers for the whole kernel
+    bf16x8 w1frag[3][2];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+            w1frag[kh][ct] = *reinterpret_cast<const bf16x8*>(a.w1 + (ct * 32 + lr) * 48 + kh * 16 + lh * 8);
+
+    // de-phase the teams once: team 1 starts half a tile late, so that its conv1_1 / epilogue falls into team 0's
+    // conv1_2 phase and vice versa (they then keep each other out of phase: whoever shares the matrix pipe slows down)
+    if (team == 1 && !(CVPCE_DBG & 1)) {
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    for (; tile < a.ntiles; tile += stride) {
+        const int n = tile / (a.tiles_x * a.tiles_y);
+        const int rem = tile - n * (a.tiles_x * a.tiles_y);
+        const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        const int next = tile + stride;
+        if (next < a.ntiles) load_patch(next);          // global loads in flight under the conv1_1 phase
+        const bool border = ty == 0 || tx == 0 || ty == a.tiles_y - 1 || tx == a.tiles_x - 1;
+
+        // ================= phase 1: conv1_1 on the 18x18 patch -> A1 =================
+        if (!(CVPCE_DBG & 4)) __builtin_amdgcn_s_setprio(2);
+        for (int pt = wid; pt < ((CVPCE_DBG & 8) ? 0 : S2_NPT); pt += 4) {
+            int pp = pt * 32 + lr;
+            const bool real = pp < S2_NPIX1;
+            if (!real) pp = S2_NPIX1 - 1;
+            const int py = pp / S2_P1, px = pp - py * S2_P1;
+            f32x16 acc[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(BL + c * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[c][4 * g + j] = b[j];
+                }
+            // B fragments: k = kh*16 + 8h + j  <->  pixels (py+kh, px+2h .. px+2h+1), 4 channels each: 16 contiguous bytes.
+            union { unsigned long long u[2]; bf16x8 v; } bfrag[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned char* src = IN + ((py + kh) * S2_P0 + px + 2 * lh) * 8;
+                bfrag[kh].u[0] = *reinterpret_cast<const unsigned long long*>(src);
+                bfrag[kh].u[1] = *reinterpret_cast<const unsigned long long*>(src + 8);
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1frag[kh][ct], bfrag[kh].v, acc[ct], 0, 0, 0);
+            // epilogue: ReLU, zero outside the image (conv1_2 pads conv1_1's OUTPUT with zeros: a mask on the packed
+            // pairs, all ones except on the tiles that touch the image border)
+            const int y = ty * S2_T - 1 + py, x = tx * S2_T - 1 + px;
+            const unsigned keep = ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) ? 0xFFFFFFFFu : 0u;
+            if (real) {
+                const int abase = (py * S2_P1 + px) * 128 + lh * 8;
+                const int aswz = (s2_swz0(px >> 1) ^ (py & 1)) << 4;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = relu_bits(acc[ct][4 * g + j]);
+                        uint2 u = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r));
+                        if (border) { u.x &= keep; u.y &= keep; }
+                        // channels co = ct*32 + 8g + 4lh .. +3 = chunk ct*4 + g, bytes lh*8 .. +7
+                        *reinterpret_cast<uint2*>(A1 + abase + (((ct * 4 + g) << 4) ^ aswz)) = u;
+                    }
+            }
+        }
+        team_barrier(cnt_addr, bar_target, lane);
+        if (next < a.ntiles) store_patch();             // IN is free again: stage the next tile's input
+
+        // ================= phase 2: conv1_2 (9 taps x 4 K-steps) out of LDS =================
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(BL + 64 + mt * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[mt][0][4 * g + j] = b[j]; acc[mt][1][4 * g + j] = b[j]; }
+            }
+        bf16x8 af[3][2], bfr[3][2];
+#define S2_LOAD(S, SLOT)                                                                                       \
+        {                                                                                                      \
+            const int tap = (S) >> 2, kk = (S) & 3;                                                            \
+            const int kh = tap / 3, kw = tap - kh * 3;                                                         \
+            const int chunk = kk * 2 + lh;                                                                     \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                 \
+                const int row = tap * 64 + mt * 32 + lr;                                                       \
+                af[SLOT][mt] = *reinterpret_cast<const bf16x8*>(W2 + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); \
+            }                                                                                                  \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
+                bfr[SLOT][nt] = *reinterpret_cast<const bf16x8*>(A1 + ((rd2[nt][kw] ^ (unsigned)(((2 * kk) ^ (kh & 1)) << 4)) + (unsigned)((kh * S2_P1 + kw) * 128))); \
+        }
+        // fragments run TWO K-steps ahead of the MFMAs (3 register slots); sched_barrier pins that order
+        if (!(CVPCE_DBG & 4)) __builtin_amdgcn_s_setprio(0);
+        if (CVPCE_DBG & 2) __builtin_amdgcn_s_setprio(2);
+        S2_LOAD(0, 0)
+        S2_LOAD(1, 1)
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 2 < 36) S2_LOAD(s + 2, (s + 2) % 3)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(CVPCE_DBG & 16))
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % 3][mt], bfr[s % 3][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef S2_LOAD
+        if (CVPCE_DBG & 2) __builtin_amdgcn_s_setprio(0);
+        if (!(CVPCE_DBG & 4)) __builtin_amdgcn_s_setprio(2);
+        // epilogue: 2x2 max over the quad's 4 lanes (DPP), ReLU.  After pooling the 4 lanes of a quad hold the
+        // same 64 values; lane `sub` keeps channel group g = sub, then a v_permlane32_swap pair gives every lane
+        // 8 consecutive channels: ONE 16-byte store per lane per pixel tile, all 64 lanes active.
+        const int Ho = a.H >> 1, Wo = a.W >> 1;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            unsigned pk[2][2];     // [mt][dword]: this lane's 4 channels (8 sub + 4 lh ..+3) of cout tile mt, bf16x2 packed
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                bf16x4 sel;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sel[j] = (bf16_t)0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 r;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = quad_max_nonneg(relu_bits(acc[mt][nt][4 * g + j]));
+                    const bf16x4 o = f32x4_to_bf16x4(r);
+                    if (sub == g) sel = o;
+                }
+                const uint2 u = *reinterpret_cast<const uint2*>(&sel);
+                pk[mt][0] = u.x; pk[mt][1] = u.y;
+            }
+            // lanes 0-31 (lh = 0) end with cout tile 0, channels 8 sub .. 8 sub + 7; lanes 32-63 with cout tile 1
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                pk[0][d] = r[0]; pk[1][d] = r[1];
+            }
+            const int oyp = (ty * S2_T) / 2 + (2 * wid + nt), oxp = (tx * S2_T) / 2 + q;
+            bf16_t* dst = a.out + ((size_t)(n * Ho + oyp) * Wo + oxp) * 64 + lh * 32 + sub * 8;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+        }
+        team_barrier(cnt_addr, bar_target, lane);        // A1 is free again; the next input patch is visible
+    }
+}
+
+extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
+                                    const float* b2, void* out, int N, int H, int W, void* stream) {
+    if (N <= 0) return CVPCE_OK;
+    if (!in_nhwc || !w1 || !b1 || !w2 || !b2 || !out) return CVPCE_ERR_ARG;
+    if (in_cstride != 4 && in_cstride != 8) return CVPCE_ERR_ARG;
+    if (H % S2_T != 0 || W % S2_T != 0 || H <= 0 || W <= 0) return CVPCE_ERR_ARG;
+    if ((long long)N * H * W >= (1LL << 31) / 64) return CVPCE_ERR_ARG;
+    Stem2Args a;
+    a.in = (const bf16_t*)in_nhwc; a.cstride = in_cstride; a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2;
+    a.out = (bf16_t*)out; a.N = N; a.H = H; a.W = W;
+    a.tiles_x = W / S2_T; a.tiles_y = H / S2_T; a.ntiles = N * a.tiles_x * a.tiles_y;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)vgg_stem2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_SMEM) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int pairs = (a.ntiles + 1) / 2;
+    const int grid = pairs < 256 ? pairs : 256;       // one persistent workgroup (two teams) per CU
+    hipLaunchKernelGGL(vgg_stem2_kernel, dim3(grid), dim3(512), S2_SMEM, (hipStream_t)stream, a);
+    return cvpce_check_launch();
+}

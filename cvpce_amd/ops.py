@@ -107,6 +107,7 @@ class ConvProfile:
 PROFILE = None   # set to a ConvProfile() to record
 
 
+USE_STEM_1Q = False          # A/B switch: first-generation fused stem (one 4-wave team per workgroup)
 USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
 HALO_RAGGED = False          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
 USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
@@ -150,7 +151,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         check(rc, 'cvpce_conv3x3_halo')
         if prof is not None:
             e1.record()
-            prof.records.append((f'conv3x3_halo_kernel<{256 if pc.cout > 128 else 128}>',
+            prof.records.append((('conv3x3_halo_kernel' if USE_HALO_RING else 'conv3x3_halo2_kernel') + ('<8,1>' if pc.cout > 128 else '<4,2>'),
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
         return out
     if resident:
@@ -199,11 +200,11 @@ def vgg_stem(x, ps):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(ps.w1), _p(ps.b1), _p(ps.w2), _p(ps.b2), _p(out), n, h, w, _stream()),
-          'cvpce_vgg_stem_fused')
+    fn = lib.cvpce_vgg_stem_fused_1q if USE_STEM_1Q else lib.cvpce_vgg_stem_fused
+    check(fn(_p(x), c, _p(ps.w1), _p(ps.b1), _p(ps.w2), _p(ps.b2), _p(out), n, h, w, _stream()), 'cvpce_vgg_stem_fused')
     if prof is not None:
         e1.record()
-        prof.records.append(('vgg_stem_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
+        prof.records.append(('vgg_stem_kernel' if USE_STEM_1Q else 'vgg_stem2_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
     return out
 
 

@@ -51,6 +51,9 @@ int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, c
  * (slots kw = 3 and c = 3 zero); w2: bf16 [9][64][64] = (tap, cout, cin); out: [N][H/2][W/2][64] bf16. */
 int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
                          const float* b2, void* out, int N, int H, int W, void* stream);
+/* Same contract, first-generation kernel (one 4-wave team per workgroup, WG-wide barriers); kept for A/B. */
+int cvpce_vgg_stem_fused_1q(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
+                            const float* b2, void* out, int N, int H, int W, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with Cin = 64 whose weights stay resident in LDS (VGG16 conv2_1): same
  * operands, weight layout ([Cout_pad][576], k = (kh*3+kw)*64 + ci) and numerics as cvpce_conv2d_nhwc_bf16; H, W

@@ -346,8 +346,16 @@ def test_match_ties_lowest_index(cuda):
     assert idx.equal(torch.arange(5).expand(3, 5))
 
 
-@pytest.mark.parametrize('n,h,w', [(2, 32, 48), (1, 256, 256), (3, 16, 16)])
-def test_vgg_stem_fused_parity(cuda, n, h, w):
+@pytest.fixture(params=[False, True], ids=['teams', '1q'])
+def stem_variant(request):
+    from cvpce_amd import ops
+    ops.USE_STEM_1Q = request.param
+    yield request.param
+    ops.USE_STEM_1Q = False
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 32, 48), (1, 256, 256), (3, 16, 16), (1, 16, 32), (37, 64, 64)])
+def test_vgg_stem_fused_parity(cuda, n, h, w, stem_variant):
     """Fused conv1_1+ReLU+conv1_2+ReLU+pool kernel against the oracle ops on the same bf16-rounded operands
     (conv1_1's output is rounded to bf16 before conv1_2, exactly like the unfused schedule stores it)."""
     from cvpce_amd import ops

@@ -1,16 +1,14 @@
 #!/bin/bash
-# dev tool: build side libraries with compile-time ablation flags of the conv kernel (see CVPCE_DBG in conv_igemm.hip)
+# dev tool: build side libraries with compile-time ablation flags (-DCVPCE_DBG=<flags>) of ONE kernel source
+# usage: ablate.sh <source-stem, e.g. conv_igemm | vgg_stem | conv3x3_halo2> flags...
+#   -> cvpce_amd/libcvpce_hip_<stem>_dbg<flags>.so ; select it with CVPCE_LIB=<path>
 set -e
 cd "$(dirname "$0")/../cvpce_amd/csrc"
 mkdir -p build
-# usage: ablate.sh <conv|stem> flags...
+make -s
 which=$1; shift
+others=$(ls build/*.o | grep -v "_dbg" | grep -v "build/$which.o")
 for d in "$@"; do
-  if [ "$which" = stem ]; then
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -DCVPCE_DBG=$d -c vgg_stem.hip -o build/vgg_stem_dbg$d.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/conv_igemm.o build/vgg_stem_dbg$d.o build/elementwise.o build/preproc.o build/detect.o build/match.o -o ../libcvpce_hip_stem$d.so
-  else
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -DCVPCE_DBG=$d -c conv_igemm.hip -o build/conv_igemm_dbg$d.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/conv_igemm_dbg$d.o build/vgg_stem.o build/elementwise.o build/preproc.o build/detect.o build/match.o -o ../libcvpce_hip_dbg$d.so
-  fi
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -DCVPCE_DBG=$d -c $which.hip -o build/${which}_dbg$d.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others build/${which}_dbg$d.o -o ../libcvpce_hip_${which}_dbg$d.so
 done
