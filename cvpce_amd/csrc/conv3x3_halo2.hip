@@ -20,6 +20,13 @@
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 
+// compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 no s_setprio around the MFMA
+// groups, 2 XCD-aware tile order, 4 no patch DMA in the loop, 8 no weight loads in the loop, 16 no output stores,
+// 32 no fragment reads in the loop
+#ifndef CVPCE_DBG
+#define CVPCE_DBG 0
+#endif
+
 #define G2_T 16
 #define G2_P 18
 #define G2_NPIX 324
@@ -38,6 +45,7 @@ struct Halo2Args {
     const bf16_t* in;    // [N][H][W][Cin]
     const bf16_t* wgt;   // [Cout_pad][K_pad], chunk-major K
     const float* bias;
+    const unsigned char* mask;   // optional [H][W]: output pixels with mask 0 are stored as zeros (atlas gaps); not with POOL
     bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]
     int N, H, W, Cin, Cout, K_pad, relu;
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
@@ -69,13 +77,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     const __amdgpu_buffer_rsrc_t srd_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
 
     const int nchunks = a.Cin >> 6;
-    const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lbid0 = (CVPCE_DBG & 2) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int my_tiles = (a.ntiles - lbid0 + (int)gridDim.x - 1) / (int)gridDim.x;
     if (my_tiles <= 0) return;
     const int total_chunks = my_tiles * nchunks;          // < 2^31: checked on the host
 
     // tile seq -> (image, tile row, tile column, cout tile); cout tile fastest
+    const int lbid = (CVPCE_DBG & 2) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct) {
-        const int t = (int)blockIdx.x + seq * (int)gridDim.x;
+        const int t = lbid + seq * (int)gridDim.x;
         ct = t % a.ctiles;
         const int p = t / a.ctiles;
         n = p / (a.tiles_x * a.tiles_y);
@@ -89,9 +99,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     const int npp = (wid == 0) ? 6 : 5;
     auto issue_patch = [&](int n, int ty, int tx, int c, int buf) {
         const int y0 = ty * G2_T - 1, x0 = tx * G2_T - 1;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));      // recompute the per-piece constants here (once per 18 K-steps): hoisted out of the
-                                          // chunk loop they would cost 18 VGPRs the accumulators need
+        // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the empty
+        // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < npp) {
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     tile_of(0, pi_n, pi_ty, pi_tx, pi_ct);
     auto issue_next_patch = [&]() {
         if (pi < total_chunks) {
-            issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
+            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
             ++pi;
             if (++pi_buf == 3) pi_buf = 0;
             if (++pi_c == nchunks) {
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     {                                                                                                          \
         _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_)                                                    \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
-                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_] + (TAP) * 128 + hf_ * 64, (SBASE), 0); \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + (TAP) * 128 + hf_ * 64, 0); \
                 af[SLOT][hf_][mt_] = __builtin_bit_cast(bf16x8, v_);                                           \
             }                                                                                                  \
     }
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
     // issue the 4 reads of group GI of K-step R18
 #define G2_READS(R18, GI)                                                                                      \
-    {                                                                                                          \
+    if constexpr (!(CVPCE_DBG & 32)) {                                                                         \
         constexpr int tap_ = (R18) >> 1, kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                 \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 0) & 7]) : "v"(e0), "n"(g2_imm<POOL>(4 * (GI) + 0, kh_, kw_))); \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 1) & 7]) : "v"(e1), "n"(g2_imm<POOL>(4 * (GI) + 1, kh_, kw_))); \
@@ -207,11 +218,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         asm volatile("s_waitcnt lgkmcnt(%4)"                                                                   \
                      : "+v"(bfr[(4 * (GI) + 0) & 7]), "+v"(bfr[(4 * (GI) + 1) & 7]), "+v"(bfr[(4 * (GI) + 2) & 7]), "+v"(bfr[(4 * (GI) + 3) & 7]) \
                      : "n"(NOUT));                                                                             \
-        __builtin_amdgcn_s_setprio(1);                                                                         \
+        if (!(CVPCE_DBG & 1)) __builtin_amdgcn_s_setprio(1);                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                                \
                 acc[mt_][4 * (GI) + i_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ts_][hf_][mt_], bfr[(4 * (GI) + i_) & 7], acc[mt_][4 * (GI) + i_], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                         \
+        if (!(CVPCE_DBG & 1)) __builtin_amdgcn_s_setprio(0);                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
     // group GI of K-step R18 (not the chunk's last group): prefetch the next group, then compute this one
@@ -230,8 +241,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // one 3x3 tap = two K-steps; first fetch the weights of the tap after next (same chunk, or the next chunk's first two)
 #define G2_TAP(T)                                                                                              \
     {                                                                                                          \
+        if constexpr (!(CVPCE_DBG & 8)) {                                                                      \
         if constexpr ((T) + 2 < 9) G2_LOAD_A(((T) + 2) % 3, sb_cur, (T) + 2)                                   \
         else G2_LOAD_A(((T) + 2) % 3, sb_next, (T) + 2 - 9)   /* past the last chunk: a harmless reload */     \
+        }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         G2_KSTEP(2 * (T))                                                                                      \
         G2_KSTEP(2 * (T) + 1)                                                                                  \
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
-        if (seq + 1 < my_tiles) return ((int)blockIdx.x + (seq + 1) * (int)gridDim.x) % a.ctiles;
+        if (seq + 1 < my_tiles) return (lbid + (seq + 1) * (int)gridDim.x) % a.ctiles;
         return t_ct;                                    // no next chunk: any valid address will do
     };
     issue_next_patch();
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
             for (int nt = 0; nt < NB; ++nt) {
                 const int nb = wp * NB + nt;
                 size_t opix;
+                bool keep = true;                // masked-out pixels (gaps of a level atlas) are stored as zeros
                 bool store_lane;                 // ragged right / bottom tiles: pixels outside the image are dropped
                 if (POOL) {
                     const int q = lp >> 2;
@@ -301,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                     const int oy = ty * G2_T + nb, ox = tx * G2_T + g2_col(lp);
                     opix = (size_t)(n * a.H + oy) * a.W + ox;
                     store_lane = oy < a.H && ox < a.W;
+                    if (a.mask && store_lane) keep = a.mask[oy * a.W + ox] != 0;
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -319,8 +334,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = quad_max(v[j]);
                     }
-                    if (store_lane && co < a.Cout)
-                        *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+                    if (store_lane && co < a.Cout && !(CVPCE_DBG & 16))
+                        *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) =
+                            keep ? f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]}) : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
                 }
             }
 #pragma unroll
@@ -364,8 +380,8 @@ static int launch_halo2(Halo2Args a, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
-extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
-                                  int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out, int N,
+                          int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 4 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
@@ -374,7 +390,8 @@ extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* 
     if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
     if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31)) return CVPCE_ERR_ARG;
     Halo2Args a;
-    a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.out = (bf16_t*)out;
+    if (mask && fuse_pool2) return CVPCE_ERR_ARG;
+    a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = mask; a.out = (bf16_t*)out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
     a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T; a.ptiles = N * a.tiles_x * a.tiles_y;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
@@ -384,4 +401,16 @@ extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (Cout > 128) return fuse_pool2 ? launch_halo2<8, 1, true>(a, s) : launch_halo2<8, 1, false>(a, s);
     return fuse_pool2 ? launch_halo2<4, 2, true>(a, s) : launch_halo2<4, 2, false>(a, s);
+}
+
+extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                                  int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+    return halo2_dispatch(in, wgt, bias, nullptr, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+}
+
+extern "C" int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                         void* out, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad,
+                                         int relu, void* stream) {
+    if (!mask) return CVPCE_ERR_ARG;
+    return halo2_dispatch(in, wgt, bias, mask, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
 }

@@ -1,0 +1,370 @@
+// 3x3 / stride 1 / pad 1 convolution for layers with FEW output channels (Cout <= 128: VGG16 conv2_1, conv2_2), Cin % 64 == 0.
+//
+// conv3x3_halo2.hip gives every wave 32 couts x 256 pixels, which needs 256 couts per workgroup; at Cout = 128 its waves
+// have to split the pixel tile instead, every weight fragment is then fetched by two waves and feeds half as many
+// MFMAs -- the weight stream costs 22 % of the layer (profiles/r01d_ablation_halo2.md).  This variant keeps the
+// 32-cout x 256-pixel wave tile by making the workgroup's pixel tile 16 rows x 32 columns: waves (wc, wp) = (cout
+// group of 32, left / right 16 columns).  To fit the larger patch the channel chunk is 32 (64-byte pixels):
+//   * patch 18 x 34 pixels x 32 channels = 38.25 KiB, triple buffered (LDS-DMA, zero-filled borders),
+//   * one K-step = one 3x3 tap of the 32-channel sub-chunk: 2 weight loads (64 B per row, straight from L2 into MFMA
+//     layout, four K-steps ahead), 16 ds_read_b128 with immediate offsets, 32 MFMA 16x16x32 per wave,
+//   * one workgroup barrier per sub-chunk (9 K-steps); the loop body is one 64-channel chunk = two sub-chunks.
+// Pixel lanes are laid out along rows in BOTH modes (lanes {0-3,12-15} = even columns, {4-11} = odd columns), which is
+// conflict-free for 64-byte pixels under the chunk ^ ((px >> 2) & 3) swizzle; the fused MaxPool2d(2,2) is a plain max
+// of two accumulator rows plus one masked row-rotate per side.
+// K order / weight layout: chunk-major [Cout_pad][K_pad] of include/cvpce_amd.h.  Fused bias / ReLU / MaxPool2d(2,2).
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+
+#define G3_TH 16
+#define G3_TW 32
+#define G3_PW 34
+#define G3_NPIX (18 * 34)
+#define G3_NPIECE 39                       // 16 pixels of 64 B per 1-KiB DMA piece
+#define G3_A_BYTES (G3_NPIECE * 1024)
+
+__device__ __forceinline__ int g3_col(int l16) { return l16 < 4 ? 2 * l16 : (l16 >= 12 ? 2 * (l16 - 8) : 2 * (l16 - 4) + 1); }
+
+struct Halo3Args {
+    const bf16_t* in;    // [N][H][W][Cin]
+    const bf16_t* wgt;   // [Cout_pad][K_pad], chunk-major K
+    const float* bias;
+    bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]
+    int N, H, W, Cin, Cout, K_pad, relu;
+    int tiles_x, tiles_y, ptiles, ctiles, ntiles;
+    unsigned in_bytes, wgt_bytes;
+};
+
+__device__ __forceinline__ constexpr int g3_imm(int nb, int kh, int kw) { return ((nb + kh) * G3_PW + kw) * 64; }
+
+template <bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
+    constexpr int TC = 128, NB = 16, NG = 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ap = smem;                 // [3][612 (+12)][32] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wid >> 1, wp = wid & 1;
+    const int l16 = lane & 15, lq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+
+    const int nchunks = a.Cin >> 6;                       // 64-channel chunks = loop bodies per tile
+    const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
+    const int total_sub = 2 * total_chunks;
+
+    auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct) {
+        const int t = (int)blockIdx.x + seq * (int)gridDim.x;
+        ct = t % a.ctiles;
+        const int p = t / a.ctiles;
+        n = p / (a.tiles_x * a.tiles_y);
+        const int r = p - n * (a.tiles_x * a.tiles_y);
+        ty = r / a.tiles_x;
+        tx = r - ty * a.tiles_x;
+    };
+
+    // ---- patch DMA: piece j fills patch pixels 16j .. 16j+15 (pixel = lane>>2, phys chunk = lane&3); pieces dealt
+    //      round-robin to the 8 waves (wave w: pieces w, w+8, ...: 5 for w < 7, else 4) ----
+    const int npp = (wid < 7) ? 5 : 4;
+    auto issue_patch = [&](int n, int ty, int tx, int c32, int buf) {
+        const int y0 = ty * G3_TH - 1, x0 = tx * G3_TW - 1;
+        // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the empty
+        // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i < npp) {
+                const int j = wid + 8 * i;
+                const int pp = j * 16 + (ln >> 2);
+                const int py = pp / G3_PW, px = pp - py * G3_PW;
+                const int lchunk = (ln & 3) ^ ((px >> 2) & 3);
+                const int y = y0 + py, x = x0 + px;
+                const bool ok = pp < G3_NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                const unsigned off = (unsigned)((((size_t)(n * a.H + y) * a.W + x) * a.Cin + c32 * 32) * 2) + (unsigned)(lchunk * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p, (lds_void*)(Ap + buf * G3_A_BYTES + j * 1024), 16,
+                                                         (int)(ok ? off : 0xFFFFFFF0u), 0, 0, 0);
+            }
+        }
+    };
+    // patch issue pointer: the next flat 32-channel sub-chunk to fetch and its tile
+    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n, pi_ty, pi_tx, pi_ct;
+    tile_of(0, pi_n, pi_ty, pi_tx, pi_ct);
+    const int nsub = 2 * nchunks;
+    auto issue_next_patch = [&]() {
+        if (pi < total_sub) {
+            issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
+            ++pi;
+            if (++pi_buf == 3) pi_buf = 0;
+            if (++pi_c == nsub) {
+                pi_c = 0;
+                ++pi_seq;
+                if (pi_seq < my_tiles) tile_of(pi_seq, pi_n, pi_ty, pi_tx, pi_ct);
+            }
+        }
+    };
+
+    // ---- weights: lane (m = l16, q = lq) loads 16 B = k 8q .. 8q+7 of row m of a 16-cout block ----
+    unsigned voff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + mt * 16 + l16) * a.K_pad + lq * 8) * 2);
+    auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)(((unsigned)(ct * TC) * (unsigned)a.K_pad + (unsigned)c * 576u) * 2u)); };
+
+    // ---- pixel fragments: address of block nb (= output row), tap (kh,kw) = (c3[kw] + buffer) + g3_imm(nb, kh, kw) ----
+    unsigned c3[3];
+    {
+        const int col = 16 * wp + g3_col(l16);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) c3[kw] = (unsigned)(col * 64 + ((lq ^ (((col + kw) >> 2) & 3)) << 4));
+    }
+    const unsigned lds_a = (unsigned)(size_t)(lds_char*)Ap;
+
+    auto load_bias = [&](int ct, f32x4* b) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
+            b[mt] = (a.bias && co < a.Cout) ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 acc[2][NB];
+    {
+        f32x4 b0[2];
+        load_bias(pi_ct, b0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = b0[i];
+    }
+
+    bf16x8 af[6][2];          // [K-step % 6][16-cout block]
+    bf16x8 bfr[8];            // pixel-fragment ring, slot = block & 7
+    unsigned e0;              // fragment base address of the K-step being fetched
+
+    // weights of K-step Q (0..17) of a body: sub-chunk Q / 9, tap Q % 9
+#define G3_LOAD_A(Q, SBASE)                                                                                    \
+    {                                                                                                          \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                                  \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + ((Q) % 9) * 128 + ((Q) / 9) * 64, 0); \
+            af[(Q) % 6][mt_] = __builtin_bit_cast(bf16x8, v_);                                                 \
+        }                                                                                                      \
+    }
+#define G3_SET_E(Q, BUFB)                                                                                      \
+    {                                                                                                          \
+        constexpr int tap_ = (Q) % 9, kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                    \
+        e0 = c3[kw_] + (BUFB);                                                                                 \
+    }
+#define G3_READS(Q, GI)                                                                                        \
+    {                                                                                                          \
+        constexpr int tap_ = (Q) % 9, kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                    \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 0) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 0, kh_, kw_))); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 1) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 1, kh_, kw_))); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 2) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 2, kh_, kw_))); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 3) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 3, kh_, kw_))); \
+    }
+#define G3_MFMAS(Q, GI, NOUT)                                                                                  \
+    {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%4)"                                                                   \
+                     : "+v"(bfr[(4 * (GI) + 0) & 7]), "+v"(bfr[(4 * (GI) + 1) & 7]), "+v"(bfr[(4 * (GI) + 2) & 7]), "+v"(bfr[(4 * (GI) + 3) & 7]) \
+                     : "n"(NOUT));                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                                \
+                acc[mt_][4 * (GI) + i_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(Q) % 6][mt_], bfr[(4 * (GI) + i_) & 7], acc[mt_][4 * (GI) + i_], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    // group GI of K-step Q, not the last group of a sub-chunk: prefetch the next group, then compute this one
+#define G3_GROUP(Q, GI)                                                                                        \
+    if constexpr ((GI) + 1 < NG) {                                                                             \
+        G3_READS(Q, (GI) + 1)                                                                                  \
+        G3_MFMAS(Q, GI, 4)                                                                                     \
+    } else if constexpr ((Q) != 8 && (Q) != 17) {                                                              \
+        G3_SET_E((Q) + 1, bufb)                                                                                \
+        G3_READS((Q) + 1, 0)                                                                                   \
+        G3_MFMAS(Q, GI, 4)                                                                                     \
+    }
+    // one K-step; first fetch the weights of K-step Q + 4 (same body, or the next body's first four)
+#define G3_KSTEP(Q)                                                                                            \
+    {                                                                                                          \
+        if constexpr ((Q) + 4 < 18) G3_LOAD_A((Q) + 4, sb_cur)                                                 \
+        else G3_LOAD_A((Q) + 4 - 18, sb_next)     /* past the last chunk: a harmless reload */                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        G3_GROUP(Q, 0) G3_GROUP(Q, 1) G3_GROUP(Q, 2) G3_GROUP(Q, 3)                                            \
+    }
+    // sub-chunk hand-off inside the last group of K-step Q (8 or 17): every wave is done with the PREVIOUS sub-chunk's
+    // buffer and (vmcnt) its own pieces of the NEXT sub-chunk's patch have landed -- at most the 8 weight loads of the
+    // next four K-steps are younger than those pieces.  After the last sub-chunk the barrier, the reads and the weight
+    // loads still run, on valid but unused data, so that the loop body has one shape.
+#define G3_HANDOFF(Q)                                                                                          \
+    {                                                                                                          \
+        const int nbufi = (bufi == 2) ? 0 : bufi + 1;                                                          \
+        const unsigned nbufb = lds_a + (unsigned)nbufi * G3_A_BYTES;                                           \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                       \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        issue_next_patch();                                                                                    \
+        G3_SET_E((Q) + 1 - ((Q) == 17 ? 18 : 0), nbufb)                                                        \
+        G3_READS((Q) + 1 - ((Q) == 17 ? 18 : 0), 0)                                                            \
+        G3_MFMAS(Q, NG - 1, 4)                                                                                 \
+        bufb = nbufb;                                                                                          \
+        bufi = nbufi;                                                                                          \
+    }
+
+    // ---- prologue ----
+    int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct;
+    tile_of(0, t_n, t_ty, t_tx, t_ct);
+    int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
+    auto next_ct = [&]() {
+        if (cchunk + 1 < nchunks) return t_ct;
+        if (seq + 1 < my_tiles) return ((int)blockIdx.x + (seq + 1) * (int)gridDim.x) % a.ctiles;
+        return t_ct;                                    // no next chunk: any valid address will do
+    };
+    issue_next_patch();
+    issue_next_patch();
+    int sb_cur = wbase(t_ct, 0);
+    n_ct = next_ct();
+    int sb_next = wbase(n_ct, (cchunk + 1 < nchunks) ? cchunk + 1 : 0);
+    G3_LOAD_A(0, sb_cur)
+    G3_LOAD_A(1, sb_cur)
+    G3_LOAD_A(2, sb_cur)
+    G3_LOAD_A(3, sb_cur)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned bufb = lds_a;                               // LDS base of the current sub-chunk's patch buffer
+    int bufi = 0;
+    G3_SET_E(0, bufb)
+    G3_READS(0, 0)
+
+    const int lp = lane & 15;
+    for (int cc = 0; cc < total_chunks; ++cc) {
+        asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
+        G3_KSTEP(0) G3_KSTEP(1) G3_KSTEP(2) G3_KSTEP(3) G3_KSTEP(4) G3_KSTEP(5) G3_KSTEP(6) G3_KSTEP(7) G3_KSTEP(8)
+        G3_HANDOFF(8)
+        G3_KSTEP(9) G3_KSTEP(10) G3_KSTEP(11) G3_KSTEP(12) G3_KSTEP(13) G3_KSTEP(14) G3_KSTEP(15) G3_KSTEP(16) G3_KSTEP(17)
+        G3_HANDOFF(17)
+        sb_cur = sb_next;
+
+        if (cchunk + 1 == nchunks) {
+            // ---- epilogue of this tile (the next tile's patch, weights and first fragments are already in flight) ----
+            const int n = t_n, ty = t_ty, tx = t_tx, ct = t_ct;
+            f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
+            load_bias(n_ct, nbias);
+            const int col = g3_col(lp);
+            if (POOL) {
+                // rows 2i, 2i+1 are blocks 2i, 2i+1 of the same lane; columns 2k, 2k+1 are lanes A[k], B[k] with
+                // A = {0-3,12-15}, B = {4-11}: lane A[k] takes its right neighbour by a row rotate (+4 for lanes 0-3,
+                // -4 for lanes 12-15; bank masks 1 and 8)
+                const int ox = tx * (G3_TW / 2) + 8 * wp + (col >> 1);
+                const bool lane_ok = (lp < 4 || lp >= 12) && ox < (a.W >> 1);
+#pragma unroll
+                for (int i = 0; i < NB / 2; ++i) {
+                    const int oy = ty * (G3_TH / 2) + i;
+                    const size_t opix = (size_t)(n * (a.H >> 1) + oy) * (a.W >> 1) + ox;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
+                        f32x4 r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (a.relu) {
+                                const unsigned v = max(__float_as_uint(relu_bits(acc[mt][2 * i][j])), __float_as_uint(relu_bits(acc[mt][2 * i + 1][j])));
+                                unsigned m = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x12C, 0xF, 0x1, false));   // row_ror:12 -> lane l reads l+4
+                                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0x8, false));            // row_ror:4  -> lane l reads l-4
+                                r[j] = __uint_as_float(m);
+                            } else {
+                                const float v = fmaxf(acc[mt][2 * i][j], acc[mt][2 * i + 1][j]);
+                                const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x12C, 0xF, 0x1, false));
+                                const float dn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x124, 0xF, 0x8, false));
+                                r[j] = fmaxf(v, fmaxf(up, dn));
+                            }
+                        }
+                        if (lane_ok && oy < (a.H >> 1) && co < a.Cout)
+                            *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = f32x4_to_bf16x4(r);
+                    }
+                }
+            } else {
+                const int ox = tx * G3_TW + 16 * wp + col;
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) {
+                    const int oy = ty * G3_TH + nt;
+                    const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
+                    const bool store_lane = oy < a.H && ox < a.W;     // ragged right / bottom tiles
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
+                        f32x4 r = acc[mt][nt];
+                        if (a.relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) r[j] = relu_bits(r[j]);
+                        }
+                        if (store_lane && co < a.Cout)
+                            *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = f32x4_to_bf16x4(r);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) acc[mt][nt] = nbias[mt];
+            cchunk = 0;
+            ++seq;
+            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct);
+        } else {
+            ++cchunk;
+        }
+        n_ct = next_ct();
+        sb_next = wbase(n_ct, (cchunk + 1 < nchunks) ? cchunk + 1 : 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
+#undef G3_HANDOFF
+#undef G3_KSTEP
+#undef G3_GROUP
+#undef G3_MFMAS
+#undef G3_READS
+#undef G3_SET_E
+#undef G3_LOAD_A
+}
+
+template <bool POOL>
+static int launch_halo3(Halo3Args a, hipStream_t stream) {
+    a.ctiles = (a.Cout + 127) / 128;
+    a.ntiles = a.ptiles * a.ctiles;
+    const int smem = 3 * G3_A_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<POOL>), dim3(grid), dim3(512), smem, stream, a);
+    return cvpce_check_launch();
+}
+
+extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                                       int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+    if (N <= 0) return CVPCE_OK;
+    if (!in || !wgt || !out) return CVPCE_ERR_ARG;
+    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 4 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
+    if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
+    if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
+    if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
+    if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31)) return CVPCE_ERR_ARG;
+    Halo3Args a;
+    a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.out = (bf16_t*)out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
+    a.tiles_x = (W + G3_TW - 1) / G3_TW; a.tiles_y = (H + G3_TH - 1) / G3_TH; a.ptiles = N * a.tiles_x * a.tiles_y;
+    a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+    a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
+    a.ctiles = a.ntiles = 0;
+    if ((long long)a.ptiles * ((Cout + 127) / 128) * (Cin / 64) >= (1LL << 29)) return CVPCE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    return fuse_pool2 ? launch_halo3<true>(a, s) : launch_halo3<false>(a, s);
+}

@@ -305,7 +305,7 @@ extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const v
     if (!in_nhwc || !w1 || !b1 || !w2 || !b2 || !out) return CVPCE_ERR_ARG;
     if (in_cstride != 4 && in_cstride != 8) return CVPCE_ERR_ARG;
     if (H % S2_T != 0 || W % S2_T != 0 || H <= 0 || W <= 0) return CVPCE_ERR_ARG;
-    if ((long long)N * H * W >= (1LL << 31) / 64) return CVPCE_ERR_ARG;
+    if ((long long)N * H * W >= (1LL << 31) / 4) return CVPCE_ERR_ARG;      // in-kernel pixel indices are 32-bit, byte offsets 64-bit
     Stem2Args a;
     a.in = (const bf16_t*)in_nhwc; a.cstride = in_cstride; a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2;
     a.out = (bf16_t*)out; a.N = N; a.H = H; a.W = W;

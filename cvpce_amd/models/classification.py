@@ -24,7 +24,8 @@ TANH_MEAN = tuple(m * 2 - 1 for m in IMAGENET_MEAN)
 TANH_STD = tuple(s * 2 for s in IMAGENET_STD)
 INPUT_SIZE = 256
 USE_FUSED_STEM = True   # A/B switch (tests compare the fused stem against the unfused conv kernels)
-MAX_EMBED_BATCH = 256  # crops per kernel schedule pass (keeps every NHWC tensor < 2^31 elements)
+import os as _os
+MAX_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 256))  # crops per kernel schedule pass (keeps every NHWC tensor < 2^31 elements)
 
 
 def _vgg_features(cfg, batch_norm):

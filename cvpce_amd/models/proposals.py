@@ -29,6 +29,7 @@ BBOX_XFORM_CLIP = math.log(1000.0 / 16)
 ANCHOR_SIZES = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in (32, 64, 128, 256, 512))
 ASPECT_RATIOS = (0.5, 1.0, 2.0)
 FPN_CHANNELS = 256
+USE_HEAD_ATLAS = True   # head towers on ONE atlas of the 5 pyramid levels (one launch per tower layer) instead of per level
 N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
 
 
@@ -319,6 +320,63 @@ class GLNEngine:
         x = ops.conv2d(x, self.g_subnet[3], act=1)
         return ops.conv2d(x, self.g_subnet[4], act=2 if self.tanh else 1, out_f32=True)  # (N,H/2,W/2,1) f32
 
+    @staticmethod
+    def atlas_layout(shapes):
+        """Placement of the pyramid levels [(H, W), ...] on one canvas: the largest level at the origin, the others in a
+        column to its right, one zero pixel between neighbours.  -> (Hc, Wc, [(oy, ox), ...])"""
+        (h0, w0), rest = shapes[0], shapes[1:]
+        offs, y = [(0, 0)], 0
+        for (h, w) in rest:
+            offs.append((y, w0 + 1))
+            y += h + 1
+        hc = max(h0, y - 1 if rest else 0)
+        wc = w0 + ((1 + max(w for _, w in rest)) if rest else 0)
+        return hc, wc, offs
+
+    def heads_atlas(self, feats):
+        """RetinaNetHead on all levels at once.  The head's weights are shared by the levels (torchvision RetinaNetHead
+        loops over the features with the same modules), so the levels are packed into one zero-separated atlas and every
+        tower layer is ONE launch of the masked halo kernel; the gaps between the levels are its zero padding."""
+        n = feats[0].shape[0]
+        shapes = [(f.shape[1], f.shape[2]) for f in feats]
+        key = tuple(shapes)
+        if getattr(self, '_atlas_key', None) != key:
+            hc, wc, offs = self.atlas_layout(shapes)
+            mask = torch.zeros(hc, wc, dtype=torch.uint8)
+            for (h, w), (oy, ox) in zip(shapes, offs):
+                mask[oy:oy + h, ox:ox + w] = 1
+            self._atlas_key, self._atlas = key, (hc, wc, offs, mask.to(self.device))
+        hc, wc, offs, mask = self._atlas
+        atlas = torch.zeros(n, hc, wc, feats[0].shape[3], dtype=feats[0].dtype, device=self.device)
+        for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
+            atlas[:, oy:oy + h, ox:ox + w] = f
+
+        def chain(tower, final):
+            t = atlas
+            for pc in tower:
+                t = ops.conv3x3_atlas(t, pc, mask, act=1)
+            o = ops.conv2d(t, final, out_f32=True)           # gap pixels hold junk here; they are never read
+            return [o[:, oy:oy + h, ox:ox + w].contiguous() for (h, w), (oy, ox) in zip(shapes, offs)]
+
+        main = torch.cuda.current_stream()
+        if not self.side_streams:
+            return chain(self.cls_tower, self.cls_out), chain(self.reg_tower, self.reg_out)
+        # the two towers are independent: the second one runs on a side stream and fills the first one's tail
+        side = self.side_streams[0]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            reg = chain(self.reg_tower, self.reg_out)
+            for r in reg:
+                r.record_stream(main)
+            atlas.record_stream(side)
+            done = torch.cuda.Event()
+            done.record(side)
+        cls = chain(self.cls_tower, self.cls_out)
+        main.wait_event(done)
+        return cls, reg
+
     def heads(self, feats):
         """cls / reg towers on the 5 pyramid levels: 10 independent conv chains.  The small levels (25x25 .. 7x7) launch
         only a handful of workgroups each, so the chains are spread over side streams to run concurrently."""
@@ -375,7 +433,7 @@ class GLNEngine:
         c2, c3, c4, c5 = self.body(batch)
         feats = self.fpn(c3, c4, c5)
         gauss = self.gaussian_branch(c2, feats[0])
-        cls, reg = self.heads(feats)
+        cls, reg = self.heads_atlas(feats) if USE_HEAD_ATLAS else self.heads(feats)
         out = self.postprocess(cls, reg, tuple(batch.shape[1:3]), resized, original, num_classes,
                                detections_per_img, conf_thresh)
         gauss = gauss.permute(0, 3, 1, 2)  # (N,1,h,w) view of the NHWC buffer (C == 1)

@@ -108,10 +108,11 @@ PROFILE = None   # set to a ConvProfile() to record
 
 
 USE_STEM_1Q = False          # A/B switch: first-generation fused stem (one 4-wave team per workgroup)
+USE_HALO_WIDE = True         # Cout <= 128: the 16x32-tile / 32-channel-chunk halo kernel (A/B switch)
 USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
 HALO_RAGGED = False          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
 USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
-USE_RESIDENT_C64 = True      # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel
+USE_RESIDENT_C64 = False     # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel (the wide halo kernel is 8 % faster on conv2_1)
 FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
 
 
@@ -137,21 +138,21 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
                 and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
     halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
             and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
-            and act in (0, 1) and pc.cout % 4 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0))   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps)
-            and (HALO_RAGGED or n * ((h + 15) // 16) * ((w + 15) // 16) * ((pc.cout + 255) // 256 if pc.cout > 128 else 1) >= 256)
+            and act in (0, 1) and pc.cout % 4 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0))   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps); the choice never depends on the batch size: a crop's embedding must not change with the crops it is batched with
             and n * h * w * pc.cin_pad * 2 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if halo:
-        fn = lib.cvpce_conv3x3_halo_ring if USE_HALO_RING else lib.cvpce_conv3x3_halo
+        wide = USE_HALO_WIDE and not USE_HALO_RING and pc.cout <= 128
+        fn = lib.cvpce_conv3x3_halo_ring if USE_HALO_RING else (lib.cvpce_conv3x3_halo_wide if wide else lib.cvpce_conv3x3_halo)
         rc = fn(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
                 pc.cout_pad, int(act), int(pool), _stream())
         check(rc, 'cvpce_conv3x3_halo')
         if prof is not None:
             e1.record()
-            prof.records.append((('conv3x3_halo_kernel' if USE_HALO_RING else 'conv3x3_halo2_kernel') + ('<8,1>' if pc.cout > 128 else '<4,2>'),
+            prof.records.append(('conv3x3_halo3_kernel' if wide else ('conv3x3_halo_kernel' if USE_HALO_RING else 'conv3x3_halo2_kernel') + ('<8,1>' if pc.cout > 128 else '<4,2>'),
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
         return out
     if resident:
@@ -188,6 +189,28 @@ class PackedStem:
         self.b1 = b1.detach().to(torch.float32).to(device)
         self.b2 = b2.detach().to(torch.float32).to(device)
         self.flops_per_pixel = 2.0 * 64 * (27 + 576)
+
+
+def conv3x3_atlas(x, pc, mask, act=1):
+    """3x3 / stride 1 / pad 1 conv over a LEVEL ATLAS x (N,H,W,Cin) bf16: several maps sharing `pc`, packed with zero
+    gaps; mask (H,W) uint8 is 1 on level pixels.  Output pixels on the gaps are written as zeros."""
+    _need_cuda(x, mask)
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mask.dtype == torch.uint8 and mask.is_contiguous()
+    n, h, w, cin = x.shape
+    assert tuple(mask.shape) == (h, w) and cin == pc.cin_pad and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad == 1
+    assert pc.cin_pad % 64 == 0 and pc.cout % 4 == 0 and act in (0, 1)
+    out = torch.empty((n, h, w, pc.cout), dtype=BF16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.cvpce_conv3x3_halo_masked(_p(x), _p(pc.weight), _p(pc.bias), _p(mask), _p(out), n, h, w, cin, pc.cout,
+                                        pc.k_pad, pc.cout_pad, int(act), _stream()), 'cvpce_conv3x3_halo_masked')
+    if prof is not None:
+        e1.record()
+        prof.records.append(('conv3x3_halo2_kernel' + ('<8,1>' if pc.cout > 128 else '<4,2>'),
+                             2.0 * float(mask.sum().item()) * n * pc.cout * 9 * pc.cin, e0, e1))
+    return out
 
 
 def vgg_stem(x, ps):

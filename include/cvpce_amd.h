@@ -67,6 +67,18 @@ int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bia
  * relu = 0/1; fuse_pool2 = 1 stores MaxPool2d(2,2) of the result ([N][H/2][W/2][Cout]). */
 int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                        int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+/* Same contract for layers with FEW output channels (Cout <= 128 per cout tile: VGG16 conv2_1 / conv2_2): 16x32-pixel
+ * tiles and 32-channel sub-chunks keep the 32-cout x 256-pixel wave tile of cvpce_conv3x3_halo, so every weight
+ * fragment is fetched once and feeds 16 MFMAs. */
+int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                            int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+/* cvpce_conv3x3_halo on a LEVEL ATLAS: several feature maps that share the conv weights (the 5 FPN levels under the
+ * RetinaNet head, torchvision RetinaNetHead reached from cvpce/models/proposals.py:166) are packed side by side into one
+ * [N][H][W][Cin] canvas with >= 1 zero pixel between them; mask is [H][W] bytes, 1 on level pixels, 0 on the gaps.
+ * Outputs on mask-0 pixels are stored as zeros, so the result is again a valid atlas (the gaps ARE the next layer's
+ * zero padding) and one launch replaces one launch per level. */
+int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out,
+                              int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu, void* stream);
 /* Same contract, first-generation kernel (weights through an LDS ring, one barrier per K-step); kept for A/B. */
 int cvpce_conv3x3_halo_ring(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                             int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);

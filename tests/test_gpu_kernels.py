@@ -103,8 +103,13 @@ def test_conv2d_parity(cuda, case):
         ref = torch.tanh(ref)
     if o.get('pool'):
         ref = F.max_pool2d(ref, 2, 2)
-    y = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev, in_up_shift=in_up,
-                   pool=o.get('pool', False))
+    ring_case = name.startswith('dma') or name.startswith('pool_dma')
+    ops.USE_HALO_3X3 = not ring_case          # these cases pin the LDS-ring implicit-GEMM kernels (the halo kernels have their own test)
+    try:
+        y = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev, in_up_shift=in_up,
+                       pool=o.get('pool', False))
+    finally:
+        ops.USE_HALO_3X3 = True
     torch.cuda.synchronize()
     got = nchw(y)
     if name.startswith('dma') or name.startswith('pool_dma'):
@@ -401,15 +406,22 @@ def test_conv3x3_c64_resident_parity(cuda, n, h, w, cout):
     pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
     ref = F.relu(F.conv2d(x, r16(wgt), bias, padding=1))
     xin = nhwc(x).to(cuda)
-    y = ops.conv2d(xin, pc, act=1)
+    ops.USE_RESIDENT_C64 = True           # (not the default dispatch any more: the wide halo kernel is faster on conv2_1)
+    ops.PROFILE = ops.ConvProfile()
+    try:
+        y = ops.conv2d(xin, pc, act=1)
+        assert ops.PROFILE.records[-1][0] == 'conv3x3_c64_kernel'
+        y3 = ops.conv2d(xin, pc, act=0)       # no ReLU
+    finally:
+        ops.USE_RESIDENT_C64 = False
+        ops.PROFILE = None
     assert rel_err(nchw(y), ref) < 1e-2
-    ops.USE_RESIDENT_C64 = False
+    ops.USE_HALO_3X3 = False
     try:
         y2 = ops.conv2d(xin, pc, act=1)
     finally:
-        ops.USE_RESIDENT_C64 = True
+        ops.USE_HALO_3X3 = True
     assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
-    y3 = ops.conv2d(xin, pc, act=0)       # no ReLU
     assert rel_err(nchw(y3), F.conv2d(x, r16(wgt), bias, padding=1)) < 1e-2
 
 
@@ -424,10 +436,13 @@ HALO_CASES = [  # n, cin, h, w, cout, pool
     (8, 256, 50, 50, 256, False),      # ... on P4
     (9, 128, 26, 38, 128, True),       # ragged + pooled (even sizes)
     (8, 256, 13, 13, 256, False),      # smaller than one tile
+    (3, 64, 48, 80, 128, False),       # conv2_1 shape class: one 64-channel chunk, Cout = 128
+    (2, 64, 30, 44, 96, True),         # ragged + pooled, Cout < 128, odd tile counts both ways
+    (2, 192, 40, 70, 128, True),       # three chunks
 ]
 
 
-@pytest.mark.parametrize('ring', [False, True])
+@pytest.mark.parametrize('ring', [False, True, 'narrow'])
 @pytest.mark.parametrize('n,cin,h,w,cout,pool', HALO_CASES)
 def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
     """Halo-patch kernels (register-weights and LDS-ring generation) against the implicit-GEMM HIP kernel on the same
@@ -439,9 +454,9 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
     bias = torch.randn(cout, generator=g) * 0.1
     pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
     xin = x.to(cuda)
-    ops.USE_RESIDENT_C64 = False
     ops.HALO_RAGGED = True
-    ops.USE_HALO_RING = ring
+    ops.USE_HALO_RING = ring is True
+    ops.USE_HALO_WIDE = ring is False      # 'narrow': the 16x16-tile kernel also for Cout <= 128
     ops.PROFILE = ops.ConvProfile()
     try:
         y = ops.conv2d(xin, pc, act=1, pool=pool)
@@ -450,9 +465,9 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
         y2 = ops.conv2d(xin, pc, act=1, pool=pool)
     finally:
         ops.USE_HALO_3X3 = True
-        ops.USE_RESIDENT_C64 = True
         ops.HALO_RAGGED = False
         ops.USE_HALO_RING = False
+        ops.USE_HALO_WIDE = True
         ops.PROFILE = None
     torch.cuda.synchronize()
     assert y.shape == y2.shape

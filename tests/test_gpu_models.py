@@ -279,3 +279,29 @@ def test_gaussian_branch_vs_reference_golden(cuda, golden_dir, tanh):
     # bf16 storage of inputs/weights/7 intermediate tensors vs the reference's fp32
     assert l2rel(out, g['gaussians']) < 3e-2, l2rel(out, g['gaussians'])
     assert (out - g['gaussians']).abs().max() < 0.05 * g['gaussians'].abs().max() + 1e-2
+
+
+@pytest.mark.parametrize('hw', [(100, 100), (64, 88), (20, 37)])
+def test_head_atlas_equals_per_level(cuda, gln_model, hw):
+    """RetinaNet head on the level atlas (one masked halo launch per tower layer) against the per-level launches."""
+    from cvpce_amd.models import proposals as P
+    model, _ = gln_model
+    eng = model.engine()
+    g = torch.Generator().manual_seed(hw[0])
+    shapes, (h, w) = [], hw
+    for _ in range(5):
+        shapes.append((h, w)); h, w = (h + 1) // 2, (w + 1) // 2
+    feats = [torch.randn(2, h, w, 256, generator=g).to(torch.bfloat16).to(cuda) for h, w in shapes]
+    hc, wc, offs = eng.atlas_layout(shapes)
+    occ = torch.zeros(hc + 2, wc + 2, dtype=torch.int32)
+    for (h, w), (oy, ox) in zip(shapes, offs):          # levels (grown by the 1-pixel halo) never overlap another level
+        assert oy + h <= hc and ox + w <= wc
+        occ[oy:oy + h + 2, ox:ox + w + 2] += 1
+        occ[oy + 1:oy + h + 1, ox + 1:ox + w + 1] += 10
+    assert int(((occ > 10) & (occ % 10 > 1)).sum()) == 0
+    cls_a, reg_a = eng.heads_atlas(feats)
+    cls_l, reg_l = eng.heads(feats)
+    torch.cuda.synchronize()
+    for a, b in zip(cls_a + reg_a, cls_l + reg_l):
+        assert a.shape == b.shape
+        assert (a - b).abs().max() <= 0.02 * b.abs().max() + 1e-3, ((a - b).abs().max(), b.abs().max())
