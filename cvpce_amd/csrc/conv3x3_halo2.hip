@@ -137,7 +137,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // ---- weights: lane (m = l16, q = lq) loads 16 B = k 8q .. 8q+7 of row m of a 16-cout block; per tap two K-halves ----
     unsigned voff[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + mt * 16 + l16) * a.K_pad + lq * 8) * 2);
+    // MFMA row m = 4q + j of block mt is cout 8q + 4mt + j of the wave's 32: after both blocks accumulator lane group q
+    // holds 8 CONSECUTIVE couts (8q .. 8q+7) of its pixel -> one 16-byte store per pixel block instead of two 8-byte ones
+    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + 8 * (l16 >> 2) + 4 * mt + (l16 & 3)) * a.K_pad + lq * 8) * 2);
     // scalar byte offset of (cout tile ct, channel chunk c): ct*TC rows down, c*576 k along
     auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)(((unsigned)(ct * TC) * (unsigned)a.K_pad + (unsigned)c * 576u) * 2u)); };
 
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     auto load_bias = [&](int ct, f32x4* b) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
+            const int co = ct * TC + wc * 32 + 8 * lq + 4 * mt;
             b[mt] = (a.bias && co < a.Cout) ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -317,26 +319,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                     store_lane = oy < a.H && ox < a.W;
                     if (a.mask && store_lane) keep = a.mask[oy * a.W + ox] != 0;
                 }
+                const int co = ct * TC + wc * 32 + 8 * lq;            // this lane's 8 consecutive couts
+                float v[8];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
-                    float v[4];
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j];
-                    if (a.relu) {
+                    for (int j = 0; j < 4; ++j) v[4 * mt + j] = acc[mt][nt][j];
+                if (a.relu) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
-                        if (POOL) {
+                    for (int j = 0; j < 8; ++j) v[j] = relu_bits(v[j]);
+                    if (POOL) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = quad_max_nonneg(v[j]);
-                        }
-                    } else if (POOL) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = quad_max(v[j]);
+                        for (int j = 0; j < 8; ++j) v[j] = quad_max_nonneg(v[j]);
                     }
-                    if (store_lane && co < a.Cout && !(CVPCE_DBG & 16))
-                        *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) =
-                            keep ? f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]}) : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                } else if (POOL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = quad_max(v[j]);
+                }
+                if (store_lane && co < a.Cout && !(CVPCE_DBG & 16)) {
+                    const bf16x4 lo = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]}), hi = f32x4_to_bf16x4(f32x4{v[4], v[5], v[6], v[7]});
+                    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = keep ? u32x4{l2.x, l2.y, h2.x, h2.y} : u32x4{0u, 0u, 0u, 0u};
                 }
             }
 #pragma unroll
@@ -384,7 +387,7 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
                           int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
-    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 4 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
+    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
     if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
     if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
     if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;

@@ -115,7 +115,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // ---- weights: lane (m = l16, q = lq) loads 16 B = k 8q .. 8q+7 of row m of a 16-cout block ----
     unsigned voff[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + mt * 16 + l16) * a.K_pad + lq * 8) * 2);
+    // MFMA row m = 4q + j of block mt is cout 8q + 4mt + j of the wave's 32: accumulator lane group q then holds 8
+    // CONSECUTIVE couts of its pixel -> one 16-byte store per pixel block
+    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + 8 * (l16 >> 2) + 4 * mt + (l16 & 3)) * a.K_pad + lq * 8) * 2);
     auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)(((unsigned)(ct * TC) * (unsigned)a.K_pad + (unsigned)c * 576u) * 2u)); };
 
     // ---- pixel fragments: address of block nb (= output row), tap (kh,kw) = (c3[kw] + buffer) + g3_imm(nb, kh, kw) ----
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     auto load_bias = [&](int ct, f32x4* b) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
+            const int co = ct * TC + wc * 32 + 8 * lq + 4 * mt;
             b[mt] = (a.bias && co < a.Cout) ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -267,26 +269,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                 for (int i = 0; i < NB / 2; ++i) {
                     const int oy = ty * (G3_TH / 2) + i;
                     const size_t opix = (size_t)(n * (a.H >> 1) + oy) * (a.W >> 1) + ox;
+                    const int co = ct * TC + wc * 32 + 8 * lq;        // this lane's 8 consecutive couts
+                    float r[8];
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
-                        f32x4 r;
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (a.relu) {
                                 const unsigned v = max(__float_as_uint(relu_bits(acc[mt][2 * i][j])), __float_as_uint(relu_bits(acc[mt][2 * i + 1][j])));
                                 unsigned m = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x12C, 0xF, 0x1, false));   // row_ror:12 -> lane l reads l+4
                                 m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0x8, false));            // row_ror:4  -> lane l reads l-4
-                                r[j] = __uint_as_float(m);
+                                r[4 * mt + j] = __uint_as_float(m);
                             } else {
                                 const float v = fmaxf(acc[mt][2 * i][j], acc[mt][2 * i + 1][j]);
                                 const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x12C, 0xF, 0x1, false));
                                 const float dn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x124, 0xF, 0x8, false));
-                                r[j] = fmaxf(v, fmaxf(up, dn));
+                                r[4 * mt + j] = fmaxf(v, fmaxf(up, dn));
                             }
                         }
-                        if (lane_ok && oy < (a.H >> 1) && co < a.Cout)
-                            *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = f32x4_to_bf16x4(r);
+                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout) {
+                        const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[0], r[1], r[2], r[3]}));
+                        const uint2 h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[4], r[5], r[6], r[7]}));
+                        *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
                 }
             } else {
@@ -296,16 +300,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                     const int oy = ty * G3_TH + nt;
                     const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
                     const bool store_lane = oy < a.H && ox < a.W;     // ragged right / bottom tiles
+                    const int co = ct * TC + wc * 32 + 8 * lq;        // this lane's 8 consecutive couts
+                    f32x4 r0 = acc[0][nt], r1 = acc[1][nt];
+                    if (a.relu) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const int co = ct * TC + wc * 32 + mt * 16 + 4 * lq;
-                        f32x4 r = acc[mt][nt];
-                        if (a.relu) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) r[j] = relu_bits(r[j]);
-                        }
-                        if (store_lane && co < a.Cout)
-                            *reinterpret_cast<bf16x4*>(a.out + opix * a.Cout + co) = f32x4_to_bf16x4(r);
+                        for (int j = 0; j < 4; ++j) { r0[j] = relu_bits(r0[j]); r1[j] = relu_bits(r1[j]); }
+                    }
+                    if (store_lane && co < a.Cout) {
+                        const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r0)), h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r1));
+                        *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
                 }
             }
@@ -352,7 +355,7 @@ extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const fl
                                        int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
-    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 4 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
+    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
     if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
     if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
     if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;

@@ -138,7 +138,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
                 and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
     halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
             and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
-            and act in (0, 1) and pc.cout % 4 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0))   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps); the choice never depends on the batch size: a crop's embedding must not change with the crops it is batched with
+            and act in (0, 1) and pc.cout % 8 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0))   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps); the choice never depends on the batch size: a crop's embedding must not change with the crops it is batched with
             and n * h * w * pc.cin_pad * 2 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
@@ -198,7 +198,7 @@ def conv3x3_atlas(x, pc, mask, act=1):
     assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mask.dtype == torch.uint8 and mask.is_contiguous()
     n, h, w, cin = x.shape
     assert tuple(mask.shape) == (h, w) and cin == pc.cin_pad and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad == 1
-    assert pc.cin_pad % 64 == 0 and pc.cout % 4 == 0 and act in (0, 1)
+    assert pc.cin_pad % 64 == 0 and pc.cout % 8 == 0 and act in (0, 1)
     out = torch.empty((n, h, w, pc.cout), dtype=BF16, device=x.device)
     prof = PROFILE
     if prof is not None:

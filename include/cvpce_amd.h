@@ -63,7 +63,7 @@ int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bia
 
 /* 3x3 / stride 1 / pad 1 convolution with Cin % 64 == 0 and the input halo patch resident in LDS (VGG16 conv2_2 ..
  * conv5_3, RetinaNet head / FPN 3x3s): same operands, weight layout and numerics as cvpce_conv2d_nhwc_bf16; any H, W
- * (ragged 16x16 tiles are masked; H, W even when pooling), Cout % 4 == 0;
+ * (ragged 16x16 tiles are masked; H, W even when pooling), Cout % 8 == 0;
  * relu = 0/1; fuse_pool2 = 1 stores MaxPool2d(2,2) of the result ([N][H/2][W/2][Cout]). */
 int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                        int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
