@@ -6,9 +6,10 @@
 // 32-cout x 256-pixel wave tile by making the workgroup's pixel tile 16 rows x 32 columns: waves (wc, wp) = (cout
 // group of 32, left / right 16 columns).  To fit the larger patch the channel chunk is 32 (64-byte pixels):
 //   * patch 18 x 34 pixels x 32 channels = 38.25 KiB, triple buffered (LDS-DMA, zero-filled borders),
-//   * one K-step = one 3x3 tap of the 32-channel sub-chunk: 2 weight loads (64 B per row, straight from L2 into MFMA
-//     layout, four K-steps ahead), 16 ds_read_b128 with immediate offsets, 32 MFMA 16x16x32 per wave,
-//   * one workgroup barrier per sub-chunk (9 K-steps); the loop body is one 64-channel chunk = two sub-chunks.
+//   * row streaming as in conv3x3_halo2.hip: a step fixes kw, holds the weights of the three taps (kh, kw) of the
+//     32-channel sub-chunk (6 loads of 64 B per row, straight from L2 into MFMA layout, one step ahead), reads each of
+//     the 18 patch rows once (ds_read_b128, immediate offsets) and issues up to 6 MFMA 16x16x32 on it,
+//   * one workgroup barrier per sub-chunk (3 steps); the loop body is one 64-channel chunk = two sub-chunks.
 // Pixel lanes are laid out along rows in BOTH modes (lanes {0-3,12-15} = even columns, {4-11} = odd columns), which is
 // conflict-free for 64-byte pixels under the chunk ^ ((px >> 2) & 3) swizzle; the fused MaxPool2d(2,2) is a plain max
 // of two accumulator rows plus one masked row-rotate per side.
@@ -37,8 +38,6 @@ struct Halo3Args {
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
 };
-
-__device__ __forceinline__ constexpr int g3_imm(int nb, int kh, int kw) { return ((nb + kh) * G3_PW + kw) * 64; }
 
 template <bool POOL>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
@@ -120,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + 8 * (l16 >> 2) + 4 * mt + (l16 & 3)) * a.K_pad + lq * 8) * 2);
     auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)(((unsigned)(ct * TC) * (unsigned)a.K_pad + (unsigned)c * 576u) * 2u)); };
 
-    // ---- pixel fragments: address of block nb (= output row), tap (kh,kw) = (c3[kw] + buffer) + g3_imm(nb, kh, kw) ----
+    // ---- pixel fragments: lane (l16, lq) reads pixel (patch row p, column 16 wp + g3_col(l16) + kw), K-quarter lq:
+    //      address = (c3[kw] + buffer) + (p * 34 + kw) * 64 ----
     unsigned c3[3];
     {
         const int col = 16 * wp + g3_col(l16);
@@ -146,75 +146,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
             for (int j = 0; j < NB; ++j) acc[i][j] = b0[i];
     }
 
-    bf16x8 af[6][2];          // [K-step % 6][16-cout block]
-    bf16x8 bfr[8];            // pixel-fragment ring, slot = block & 7
-    unsigned e0;              // fragment base address of the K-step being fetched
+    bf16x8 af[2][3][2];       // [step parity][kh][16-cout block]
+    bf16x8 bfr[4];            // patch-row ring
+    unsigned e0;              // fragment base address of the step being fetched
 
-    // weights of K-step Q (0..17) of a body: sub-chunk Q / 9, tap Q % 9
-#define G3_LOAD_A(Q, SBASE)                                                                                    \
+    // ROW STREAMING (see conv3x3_halo2.hip): step T = sub-chunk * 3 + kw of a body (0..5) holds the weights of the three
+    // taps (kh, kw) of its 32 channels, reads each of the 18 patch rows once and issues up to 6 MFMAs on it.
+#define G3_LOAD_A(T, SBASE)                                                                                    \
     {                                                                                                          \
-        _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                                  \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + ((Q) % 9) * 128 + ((Q) / 9) * 64, 0); \
-            af[(Q) % 6][mt_] = __builtin_bit_cast(bf16x8, v_);                                                 \
-        }                                                                                                      \
+        _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + (kh_ * 3 + (T) % 3) * 128 + ((T) / 3) * 64, 0); \
+                af[(T) & 1][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);                                        \
+            }                                                                                                  \
     }
-#define G3_SET_E(Q, BUFB)                                                                                      \
+#define G3_SET_E(T, BUFB) { e0 = c3[(T) % 3] + (BUFB); }
+    // read patch row P of step T into ring slot (P + 2 T) & 3 (a step has 18 rows, 18 = 2 mod 4)
+#define G3_READ(T, P)                                                                                          \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[((P) + 2 * (T)) & 3]) : "v"(e0), "n"(((P) * G3_PW + (T) % 3) * 64));
+    // the MFMAs of patch row P: output rows P (kh = 0), P-1 (kh = 1), P-2 (kh = 2) where they exist
+#define G3_ROW(T, P)                                                                                           \
     {                                                                                                          \
-        constexpr int tap_ = (Q) % 9, kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                    \
-        e0 = c3[kw_] + (BUFB);                                                                                 \
-    }
-#define G3_READS(Q, GI)                                                                                        \
-    {                                                                                                          \
-        constexpr int tap_ = (Q) % 9, kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                    \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 0) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 0, kh_, kw_))); \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 1) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 1, kh_, kw_))); \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 2) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 2, kh_, kw_))); \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[(4 * (GI) + 3) & 7]) : "v"(e0), "n"(g3_imm(4 * (GI) + 3, kh_, kw_))); \
-    }
-#define G3_MFMAS(Q, GI, NOUT)                                                                                  \
-    {                                                                                                          \
-        asm volatile("s_waitcnt lgkmcnt(%4)"                                                                   \
-                     : "+v"(bfr[(4 * (GI) + 0) & 7]), "+v"(bfr[(4 * (GI) + 1) & 7]), "+v"(bfr[(4 * (GI) + 2) & 7]), "+v"(bfr[(4 * (GI) + 3) & 7]) \
-                     : "n"(NOUT));                                                                             \
-        __builtin_amdgcn_s_setprio(1);                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
-            _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                                \
-                acc[mt_][4 * (GI) + i_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(Q) % 6][mt_], bfr[(4 * (GI) + i_) & 7], acc[mt_][4 * (GI) + i_], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[((P) + 2 * (T)) & 3]));                                 \
+        _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
+            if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
+                _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                            \
+                    acc[mt_][(P) - kh_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(T) & 1][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_], 0, 0, 0); \
+            }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
-    // group GI of K-step Q, not the last group of a sub-chunk: prefetch the next group, then compute this one
-#define G3_GROUP(Q, GI)                                                                                        \
-    if constexpr ((GI) + 1 < NG) {                                                                             \
-        G3_READS(Q, (GI) + 1)                                                                                  \
-        G3_MFMAS(Q, GI, 4)                                                                                     \
-    } else if constexpr ((Q) != 8 && (Q) != 17) {                                                              \
-        G3_SET_E((Q) + 1, bufb)                                                                                \
-        G3_READS((Q) + 1, 0)                                                                                   \
-        G3_MFMAS(Q, GI, 4)                                                                                     \
-    }
-    // one K-step; first fetch the weights of K-step Q + 4 (same body, or the next body's first four)
-#define G3_KSTEP(Q)                                                                                            \
+#define G3_RP(T, P) G3_READ(T, (P) + 2) G3_ROW(T, P)
+#define G3_ROWS_0_15(T)                                                                                        \
+    G3_RP(T, 0) G3_RP(T, 1) G3_RP(T, 2) G3_RP(T, 3) G3_RP(T, 4) G3_RP(T, 5) G3_RP(T, 6) G3_RP(T, 7)            \
+    G3_RP(T, 8) G3_RP(T, 9) G3_RP(T, 10) G3_RP(T, 11) G3_RP(T, 12) G3_RP(T, 13) G3_RP(T, 14) G3_RP(T, 15)
+    // step inside a sub-chunk (T = 0, 1, 3, 4): fetch the next step's weights, stream the rows; rows 16, 17 prefetch
+    // rows 0, 1 of step T + 1 from the same buffer
+#define G3_STEP(T)                                                                                             \
     {                                                                                                          \
-        if constexpr ((Q) + 4 < 18) G3_LOAD_A((Q) + 4, sb_cur)                                                 \
-        else G3_LOAD_A((Q) + 4 - 18, sb_next)     /* past the last chunk: a harmless reload */                 \
+        G3_LOAD_A((T) + 1, sb_cur)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        G3_GROUP(Q, 0) G3_GROUP(Q, 1) G3_GROUP(Q, 2) G3_GROUP(Q, 3)                                            \
+        G3_ROWS_0_15(T)                                                                                        \
+        G3_SET_E((T) + 1, bufb)                                                                                \
+        G3_READ((T) + 1, 0) G3_ROW(T, 16)                                                                      \
+        G3_READ((T) + 1, 1) G3_ROW(T, 17)                                                                      \
     }
-    // sub-chunk hand-off inside the last group of K-step Q (8 or 17): every wave is done with the PREVIOUS sub-chunk's
-    // buffer and (vmcnt) its own pieces of the NEXT sub-chunk's patch have landed -- at most the 8 weight loads of the
-    // next four K-steps are younger than those pieces.  After the last sub-chunk the barrier, the reads and the weight
-    // loads still run, on valid but unused data, so that the loop body has one shape.
-#define G3_HANDOFF(Q)                                                                                          \
+    // last step of a sub-chunk (T = 2 or 5) with the hand-off: every wave is done with the PREVIOUS sub-chunk's buffer
+    // and (vmcnt) its own pieces of the NEXT sub-chunk's patch have landed -- at most the 6 weight loads just issued are
+    // younger than those pieces.  After the last sub-chunk the barrier, the reads and the weight loads still run, on
+    // valid but unused data, so that the loop body has one shape.
+#define G3_STEP_HANDOFF(T, TN, SBN)                                                                            \
     {                                                                                                          \
+        G3_LOAD_A(TN, SBN)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        G3_ROWS_0_15(T)                                                                                        \
         const int nbufi = (bufi == 2) ? 0 : bufi + 1;                                                          \
         const unsigned nbufb = lds_a + (unsigned)nbufi * G3_A_BYTES;                                           \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                       \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
         __builtin_amdgcn_s_barrier();                                                                          \
         issue_next_patch();                                                                                    \
-        G3_SET_E((Q) + 1 - ((Q) == 17 ? 18 : 0), nbufb)                                                        \
-        G3_READS((Q) + 1 - ((Q) == 17 ? 18 : 0), 0)                                                            \
-        G3_MFMAS(Q, NG - 1, 4)                                                                                 \
+        G3_SET_E(TN, nbufb)                                                                                    \
+        G3_READ(TN, 0) G3_ROW(T, 16)                                                                           \
+        G3_READ(TN, 1) G3_ROW(T, 17)                                                                           \
         bufb = nbufb;                                                                                          \
         bufi = nbufi;                                                                                          \
     }
@@ -234,23 +226,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     n_ct = next_ct();
     int sb_next = wbase(n_ct, (cchunk + 1 < nchunks) ? cchunk + 1 : 0);
     G3_LOAD_A(0, sb_cur)
-    G3_LOAD_A(1, sb_cur)
-    G3_LOAD_A(2, sb_cur)
-    G3_LOAD_A(3, sb_cur)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     unsigned bufb = lds_a;                               // LDS base of the current sub-chunk's patch buffer
     int bufi = 0;
     G3_SET_E(0, bufb)
-    G3_READS(0, 0)
+    G3_READ(0, 0)
+    G3_READ(0, 1)
 
     const int lp = lane & 15;
     for (int cc = 0; cc < total_chunks; ++cc) {
         asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
-        G3_KSTEP(0) G3_KSTEP(1) G3_KSTEP(2) G3_KSTEP(3) G3_KSTEP(4) G3_KSTEP(5) G3_KSTEP(6) G3_KSTEP(7) G3_KSTEP(8)
-        G3_HANDOFF(8)
-        G3_KSTEP(9) G3_KSTEP(10) G3_KSTEP(11) G3_KSTEP(12) G3_KSTEP(13) G3_KSTEP(14) G3_KSTEP(15) G3_KSTEP(16) G3_KSTEP(17)
-        G3_HANDOFF(17)
+        G3_STEP(0) G3_STEP(1)
+        G3_STEP_HANDOFF(2, 3, sb_cur)
+        G3_STEP(3) G3_STEP(4)
+        G3_STEP_HANDOFF(5, 0, sb_next)
         sb_cur = sb_next;
 
         if (cchunk + 1 == nchunks) {
@@ -326,11 +316,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         sb_next = wbase(n_ct, (cchunk + 1 < nchunks) ? cchunk + 1 : 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
-#undef G3_HANDOFF
-#undef G3_KSTEP
-#undef G3_GROUP
-#undef G3_MFMAS
-#undef G3_READS
+#undef G3_STEP_HANDOFF
+#undef G3_STEP
+#undef G3_ROWS_0_15
+#undef G3_RP
+#undef G3_ROW
+#undef G3_READ
 #undef G3_SET_E
 #undef G3_LOAD_A
 }

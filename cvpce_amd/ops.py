@@ -152,7 +152,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         check(rc, 'cvpce_conv3x3_halo')
         if prof is not None:
             e1.record()
-            prof.records.append(('conv3x3_halo3_kernel' if wide else ('conv3x3_halo_kernel' if USE_HALO_RING else 'conv3x3_halo2_kernel') + ('<8,1>' if pc.cout > 128 else '<4,2>'),
+            prof.records.append(('conv3x3_halo3_kernel' if wide else ('conv3x3_halo_kernel' if USE_HALO_RING else 'conv3x3_halo2_kernel') ,
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
         return out
     if resident:
@@ -208,7 +208,7 @@ def conv3x3_atlas(x, pc, mask, act=1):
                                         pc.k_pad, pc.cout_pad, int(act), _stream()), 'cvpce_conv3x3_halo_masked')
     if prof is not None:
         e1.record()
-        prof.records.append(('conv3x3_halo2_kernel' + ('<8,1>' if pc.cout > 128 else '<4,2>'),
+        prof.records.append(('conv3x3_halo2_kernel' ,
                              2.0 * float(mask.sum().item()) * n * pc.cout * 9 * pc.cin, e0, e1))
     return out
 
