@@ -223,6 +223,99 @@ def main():
                       'hypotheses': [(float(sc), int(a), int(b)) for sc, a, b in hyp],
                       'matching': sorted((int(a), int(b)) for a, b in match)})
     torch.save(plano, os.path.join(HERE, 'planograms.pt'))
+
+    # ---- 5. dataset readers (cvpce/datautils.py:142-165,195-220,320-387,637-670,709-739; planogram_adapters.py:17-122) ----
+    # index builders only: pure csv / json / os / re / torch / networkx.  Inputs are tiny synthetic files written to a temp
+    # dir; the fixture stores their text together with what the reference's builders return.
+    import json, tempfile
+    from cvpce import datautils as ref_du
+    from cvpce import planogram_adapters as ref_pa
+    files = {}
+
+    def put(root, rel, text):
+        full = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        with open(full, 'w') as f:
+            f.write(text)
+        files[rel] = text
+
+    with tempfile.TemporaryDirectory() as root:
+        # SKU-110K: 8 columns, rows of one image not contiguous, a skipped image, a malformed row
+        put(root, 'sku/annotations.csv', '\n'.join([
+            'test_0.jpg,10,20,110,220,object,1000,1500', 'test_1.jpg,5,6,50,60,object,800,600',
+            'test_0.jpg,200,210,300,400,object,1000,1500', 'bad,row,only', 'train_882.jpg,1,2,3,4,object,10,10',
+            'test_2.jpg,0,0,9,9,object,64,48', 'test_1.jpg,100,100,150,160,object,800,600']) + '\n')
+        sku = ref_du.SKU110KDataset.build_index(None, os.path.join(root, 'sku/annotations.csv'), ['train_882.jpg'])
+        # GP baseline: header + 6 columns
+        put(root, 'base/gt.csv', '\n'.join([
+            'image,x1,y1,x2,y2,class', 'store1_12.jpg,10,10,50,60,object', 'store2_3.jpg,1,2,30,40,object',
+            'store1_12.jpg,100,110,150,160,object', 'notastore.jpg,1,1,2,2,object', 'short,row']) + '\n')
+        base = ref_du.GPBaselineDataset.build_index(None, os.path.join(root, 'imgs'), os.path.join(root, 'base/gt.csv'))
+        base = [{**e, 'image_path': os.path.relpath(e['image_path'], root)} for e in base]
+        # GP-180: per-image csv, spaces after the commas
+        put(root, 'ann/s1_15.csv', 'Food/Candy/12.jpg, 10, 20, 110, 220\nFood/Tea/3.jpg, 200, 20, 310, 230\nFood/Candy/12.jpg, 400, 20, 500, 225\n')
+        put(root, 'ann/s2_3.csv', 'Food/Tea/3.jpg, 1, 2, 30, 40\nDrinks/Juice/7.jpg, 50, 2, 90, 44\nmalformed, row\n')
+        put(root, 'ann/s3_111.csv', 'Food/Rice/9.jpg, 5, 5, 55, 75\n')
+        put(root, 'ann/notes.txt', 'not an annotation file\n')
+        ts = ref_du.GroceryProductsTestSet.__new__(ref_du.GroceryProductsTestSet)
+        ts.image_dir = 'TESTIMGS'
+        gp180 = {}
+        for key, (only, skip) in {'all': (None, None), 'only': (['s2_3.csv', 's3_111.csv'], None), 'skip': (None, ['s1_15.csv'])}.items():
+            idx = ts.build_index(os.path.join(root, 'ann'), only, skip)
+            gp180[key] = sorted(({'id': e['id'], 'path': e['path'], 'anns': e['anns'], 'boxes': e['boxes']} for e in idx),
+                                key=lambda e: e['id'])
+        # GP training tree (+ TrainingFiles.txt)
+        tree = ['Training/Food/Candy/1.jpg', 'Training/Food/Candy/2.png', 'Training/Food/Tea/Green/10.jpg',
+                'Training/Food/Tea/Originals/11.jpg', 'Training/Food/Tea/original/12.jpg', 'Training/Background/b1.jpg',
+                'Training/Drinks/Juice/7.jpg', 'Training/Drinks/.DS_Store', 'Training/Drinks/Juice/index.txt',
+                'Training/Food/Thumbs.db', 'Training/Drinks/Juice/noextension']
+        for rel in tree:
+            put(root, 'gp/' + rel, 'x')
+        put(root, 'gp/TrainingFiles.txt', '\n'.join(['Training/Food/Candy/1.jpg', 'Training/Food/Tea/Green/10.jpg',
+                                                       'Training/Background/b1.jpg', 'Training/Drinks/Juice/7.jpg', '']) + '\n')
+        import re
+        default_skip = re.compile('|'.join(f'({s})' for s in [r'^Background.*$', r'^.*/[Oo]riginals?$']))
+        gds = ref_du.GroceryProductsDataset.__new__(ref_du.GroceryProductsDataset)
+        walk = {}
+        for key, only in {'all': None, 'only_food': ['Food']}.items():
+            try:
+                p_, c_, a_ = gds.build_index([os.path.join(root, 'gp/Training')], default_skip, only, False)
+            except AttributeError:      # 'noextension' makes the reference crash (None.group): captured as such
+                p_ = c_ = a_ = None
+            walk[key] = None if p_ is None else sorted(zip([os.path.relpath(x, root) for x in p_], c_, a_))
+        os.remove(os.path.join(root, 'gp/Training/Drinks/Juice/noextension'))
+        files.pop('gp/Training/Drinks/Juice/noextension')
+        for key, only in {'all_clean': None, 'only_food_clean': ['Food']}.items():
+            p_, c_, a_ = gds.build_index([os.path.join(root, 'gp/Training')], default_skip, only, False)
+            walk[key] = sorted(zip([os.path.relpath(x, root) for x in p_], c_, a_))
+        p_, c_, a_ = gds.build_index_from_file([os.path.join(root, 'gp')], default_skip, None)
+        walk['from_file'] = list(zip([os.path.relpath(x, root) for x in p_], c_, a_))
+        # Tonioni planograms: grids with 8-neighbourhood links, objects of different sizes, one ragged last row
+        def tonioni(rows, cols, sizes, missing=()):
+            cells = [(r, c) for r in range(rows) for c in range(cols) if (r, c) not in missing]
+            ident = {rc: i for i, rc in enumerate(cells)}
+            dirs = {'n': (-1, 0), 's': (1, 0), 'e': (0, 1), 'w': (0, -1), 'ne': (-1, 1), 'nw': (-1, -1), 'se': (1, 1), 'sw': (1, -1)}
+            graph = [{'ogg': (r * 5 + c * 3) % len(sizes), **{k: ident.get((r + dr, c + dc), -1) for k, (dr, dc) in dirs.items()}}
+                     for r, c in cells]
+            objects = [{'width': w, 'height': h, 'img_path': f'Food/Cat{i}/{10 + i}.jpg'} for i, (w, h) in enumerate(sizes)]
+            return {'graph': graph, 'objects': objects}
+        planos = {}
+        for name, spec in {'s1_15.json': (2, 3, [(10, 20), (14, 18)], ()), 's2_3.json': (3, 5, [(60, 90), (45, 100), (70, 80)], ()),
+                           's3_111.json': (4, 7, [(30, 40), (36, 52), (25, 44), (41, 40)], ((3, 6), (3, 5)))}.items():
+            put(root, 'plano/' + name, json.dumps(tonioni(*spec)))
+            b_, l_, g_ = ref_pa.read_tonioni_planogram(os.path.join(root, 'plano/' + name))
+            planos[name] = {'boxes': b_, 'labels': l_, 'nodes': sorted((int(n), d['label']) for n, d in g_.nodes(data=True)),
+                            'edges': sorted((int(a), int(b), d['dir']) for a, b, d in g_.edges(data=True))}
+        # internal planogram set
+        put(root, 'internal/index.json', json.dumps([{'image': 'a.png', 'planogram': 'a.json', 'correct': 7, 'facings': 9},
+                                                     {'image': 'b.png', 'planogram': 'b.json', 'correct': 4, 'facings': 4}]))
+        put(root, 'internal/a.json', json.dumps([{'code': '570', 'box': [0, 0, 10, 20]}, {'code': '571', 'box': [12, 0, 22, 30]},
+                                                 {'code': '570', 'box': [0, 35, 10, 50]}]))
+        put(root, 'internal/b.json', json.dumps([{'code': '9', 'box': [1.5, 2.5, 3.5, 8.0]}]))
+        internal = ref_du.InternalPlanoSet.build_index(None, os.path.join(root, 'internal'))
+        internal = [{**e, 'img': os.path.relpath(e['img'], root)} for e in internal]
+    torch.save({'files': files, 'sku110k': sku, 'gpbaseline': base, 'gp180': gp180, 'gp_walk': walk, 'tonioni': planos,
+                'internal': internal}, os.path.join(HERE, 'datasets.pt'))
     print('golden fixtures written to', HERE)
 
 
