@@ -1,4 +1,5 @@
-"""The hot-path member of /root/reference/cvpce/datautils.py (dataset readers are out of scope)."""
+"""Counterpart of /root/reference/cvpce/datautils.py: the hot-path member (`resize_for_classification`, on the GPU) and the
+host-side dataset readers of the eval commands (below)."""
 import torch
 
 from . import ops

@@ -1,7 +1,7 @@
 """Detector-only evaluation harness -- counterpart of /root/reference/cvpce/proposals_eval.py:9-48
 (`load_gln`, `evaluate_gln_sync`; the multiprocess `evaluate_gln_async` :50-87 only changes where the CPU metric
 code runs).  The per-image triple handed to the metric routine is the reference's: (target boxes, predicted boxes,
-scores).  Dataset readers are out of scope: `dataset` is any iterable of `(image (3,H,W) f32 in [0,1],
+scores).  `dataset` is any of the readers in datautils.py, or any iterable of `(image (3,H,W) f32 in [0,1],
 target dict with 'boxes' (T,4))`."""
 import torch
 
