@@ -20,6 +20,13 @@ def wrapped(x, pc, **kw):
     recs.append((tuple(x.shape), pc.cout, pc.kh, pc.stride, e0, e1, 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * pc.cout * pc.kh * pc.kw * pc.cin * (4 if kw.get('pool') else 1)))
     return y
 ops.conv2d = wrapped
+orig_atlas = ops.conv3x3_atlas
+def wrapped_atlas(x, pc, mask, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); y = orig_atlas(x, pc, mask, **kw); e1.record()
+    recs.append((('atlas',) + tuple(x.shape[1:]), pc.cout, pc.kh, pc.stride, e0, e1, 2.0 * float(mask.sum()) * x.shape[0] * pc.cout * 9 * pc.cin))
+    return y
+ops.conv3x3_atlas = wrapped_atlas
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); eng.detect(imgs, 1, 200); e1.record()
 torch.cuda.synchronize()
@@ -28,7 +35,7 @@ tot = 0
 agg = {}
 for shp, cout, k, s, a, b, fl in recs:
     ms = a.elapsed_time(b); tot += ms
-    key = (shp[1:], cout, k, s)
+    key = (shp[1:] if shp[0] != 'atlas' else shp, cout, k, s)
     d = agg.setdefault(key, [0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl
 print('sum conv ms', tot)
 for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
