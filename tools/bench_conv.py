@@ -30,6 +30,7 @@ ap.add_argument('--resident', action='store_true')
 ap.add_argument('--no-halo', action='store_true')
 ap.add_argument('--ring', action='store_true')
 ap.add_argument('--stem1q', action='store_true')
+ap.add_argument('--relu-input', action='store_true', help='post-ReLU-like input (half zeros, non-negative) instead of N(0,1): the data regime of the real pipeline (matters: the MFMA kernels are power-limited)')
 ap.add_argument('--no-wide', action='store_true')
 ap.add_argument('--stem', action='store_true', help='time the fused VGG stem kernel on 256 crops')
 args = ap.parse_args()
@@ -56,6 +57,8 @@ for name in args.layers.split(','):
     g = torch.Generator().manual_seed(0)
     pc = ops.PackedConv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.zeros(cout), stride, pad, device=dev)
     x = (torch.randn(n, h, w, pc.cin_pad, generator=g)).to(torch.bfloat16).to(dev)
+    if args.relu_input:
+        x = torch.relu(x)
     for _ in range(2):
         y = ops.conv2d(x, pc, act=1, pool=pool)
     torch.cuda.synchronize()
