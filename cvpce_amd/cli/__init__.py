@@ -139,10 +139,14 @@ def dihe():
 def dihe_eval(img_dir, test_imgs, annotations, model, resnet_layers, batch_norm, batch_size, dataloader_workers, enc_weights,
               only, knn):
     """Evaluate classification performance."""
-    if model != 'vgg16' or batch_norm:
-        raise click.UsageError('only the vgg16 (no batch norm) encoder is on the MI355X hot path (DESIGN.md 6)')
     if enc_weights is None:
         raise click.UsageError('--enc-weights is required: ImageNet weights cannot be downloaded here')
+    if model == 'vgg16':
+        encoder = classification.macvgg_embedder(model='vgg16_bn' if batch_norm else 'vgg16', pretrained=False).cuda()
+    else:
+        encoder = classification.macresnet_encoder(pretrained=False, desc_layers=list(resnet_layers)).cuda()
+    encoder.load_state_dict(torch.load(enc_weights, map_location='cpu')[EMBEDDER_STATE_DICT_KEY])
+    encoder.eval().requires_grad_(False)
     sampleset = datautils.GroceryProductsDataset(img_dir, include_annotations=True)
     only_list = skip_list = None
     if only == 'test':
@@ -150,7 +154,7 @@ def dihe_eval(img_dir, test_imgs, annotations, model, resnet_layers, batch_norm,
     elif only == 'val':
         only_list = GP_TEST_VALIDATION_SET_SIZE
     testset = datautils.GroceryProductsTestSet(test_imgs, annotations, only=only_list, skip=skip_list)
-    accuracy = classification_eval.eval_dihe(_load_encoder(enc_weights), sampleset, testset, batch_size, 0, k=knn, verbose=True)
+    accuracy = classification_eval.eval_dihe(encoder, sampleset, testset, batch_size, 0, k=knn, verbose=True)
     print(f'--> accuracy {accuracy}')
 
 

@@ -1,7 +1,7 @@
 """MAC-VGG16 product embedder + cosine matcher on MI355X -- drop-in for
 /root/reference/cvpce/models/classification.py (`MACVGG`, `macvgg_embedder`,
-`distance`, `nearest_neighbors`; inference only -- the GAN wrappers and
-MACResNet are training / optional).
+`distance`, `nearest_neighbors`, and the optional `MACResNet` / `macresnet_encoder`
+at the end of the file; inference only -- the GAN wrappers are training code).
 
 nn.Modules hold parameters under the reference's state-dict keys
 (`block1.{0,2,5,...}`, `block2.{24,26,28}`: torchvision `features` indices
@@ -120,6 +120,7 @@ class MACVGG(nn.Module):
     """classification.py:20-51.  forward((B,3,256,256) in [-1,1]) -> (B,1024) unit-norm MAC descriptor."""
 
     embedding_size = 512 * 2
+    input_mean, input_std = TANH_MEAN, TANH_STD
 
     def __init__(self, config='D', convs_per_block=[2, 2, 3, 3, 3], batch_norm=True, vgg_state_dict=None):
         super().__init__()
@@ -192,3 +193,137 @@ def macvgg_embedder(model='vgg16_bn', pretrained=True, progress=True):
         raise RuntimeError('pretrained VGG weights cannot be downloaded here; use pretrained=False and load_state_dict')
     config, batchnorm = model_to_config[model]
     return MACVGG(config, batch_norm=batchnorm)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MACResNet: the optional ResNet-50 MAC encoder (classification.py:53-85,111-121), selectable in
+# `cvpce dihe eval --model resnet50`.  Same kernels as the detector's ResNet body, eval-mode BatchNorm folded in.
+# ---------------------------------------------------------------------------------------------------------------------
+class _ResBottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (v1.5: stride on the 3x3) as a parameter container."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample, norm_layer):
+        super().__init__()
+        self.conv1, self.bn1 = nn.Conv2d(inplanes, planes, 1, bias=False), norm_layer(planes)
+        self.conv2, self.bn2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False), norm_layer(planes)
+        self.conv3, self.bn3 = nn.Conv2d(planes, planes * 4, 1, bias=False), norm_layer(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = (nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), norm_layer(planes * 4))
+                           if downsample else None)
+        self.stride = stride
+
+
+class _ResNetSource(nn.Module):
+    """The attributes of torchvision's ResNet that MACResNet reads (conv1, bn1, relu, maxpool, layer1..4)."""
+
+    def __init__(self, layers=(3, 4, 6, 3), norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.conv1, self.bn1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False), norm_layer(64)
+        self.relu, self.maxpool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+        inpl = 64
+        for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), layers)):
+            seq = []
+            for bi in range(blocks):
+                seq.append(_ResBottleneck(inpl, planes, 2 if (bi == 0 and li > 0) else 1, bi == 0, norm_layer))
+                inpl = planes * 4
+            setattr(self, f'layer{li + 1}', nn.Sequential(*seq))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+
+class MACResNetEngine:
+    def __init__(self, model, device):
+        def fold(conv, bn):
+            scale = shift = None
+            if isinstance(bn, nn.BatchNorm2d):
+                scale = bn.weight * (bn.running_var + bn.eps).rsqrt()
+                shift = bn.bias - bn.running_mean * scale
+            return ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], scale=scale, shift=shift, device=device)
+
+        self.blocks = []          # per descriptor block: list of ('stem', pc) | ('bottleneck', (c1, c2, c3, ds))
+        for block in model.blocks:
+            stages = []
+            for layer in block:
+                if isinstance(layer[0], nn.Conv2d):           # Sequential(conv1, bn1, relu, maxpool)
+                    stages.append(('stem', fold(layer[0], layer[1])))
+                else:
+                    for b in layer:
+                        stages.append(('bottleneck', (fold(b.conv1, b.bn1), fold(b.conv2, b.bn2), fold(b.conv3, b.bn3),
+                                                      fold(b.downsample[0], b.downsample[1]) if b.downsample is not None else None)))
+            self.blocks.append(stages)
+        self.device, self.embedding_size = device, model.embedding_size
+
+    def embed_packed(self, x, eps=1e-8):
+        """x: (B,S,S,8) bf16 -> (B, embedding_size) f32 unit-norm."""
+        outs = []
+        for s in range(0, x.shape[0], MAX_EMBED_BATCH):
+            xb = x[s:s + MAX_EMBED_BATCH]
+            desc = torch.empty((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)
+            off = 0
+            for stages in self.blocks:
+                for kind, p in stages:
+                    if kind == 'stem':
+                        xb = ops.maxpool2d(ops.conv2d(xb, p, act=1), 3, 2, 1)
+                    else:
+                        c1, c2, c3, ds = p
+                        identity = ops.conv2d(xb, ds) if ds is not None else xb
+                        y = ops.conv2d(ops.conv2d(xb, c1, act=1), c2, act=1)
+                        xb = ops.conv2d(y, c3, act=1, residual=identity)
+                ops.global_max_into(xb, desc, off)
+                off += xb.shape[3]
+            outs.append(ops.l2_normalize(desc, eps))
+        return torch.cat(outs) if outs else torch.empty((0, self.embedding_size), dtype=torch.float32, device=x.device)
+
+
+class MACResNet(nn.Module):
+    """classification.py:53-85.  forward((B,3,H,W)) -> (B, sum of the descriptor layers' channels) unit-norm MAC descriptor;
+    `blocks[i]` = the ResNet stages between descriptor layer i-1 (exclusive) and i (inclusive), 0 = stem."""
+    layer_output_sizes = [64, 256, 512, 1024, 2048]
+    input_mean, input_std = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)      # no normalisation inside the module (classification.py:77-84)
+
+    def __init__(self, source_resnet, descriptor_layers=[2, 3]):
+        super().__init__()
+        layers = [nn.Sequential(source_resnet.conv1, source_resnet.bn1, source_resnet.relu, source_resnet.maxpool),
+                  source_resnet.layer1, source_resnet.layer2, source_resnet.layer3, source_resnet.layer4]
+        prev = 0
+        self.blocks = nn.ModuleList()
+        for l in descriptor_layers:
+            self.blocks.append(nn.Sequential(*layers[prev:l + 1]))
+            prev = l + 1
+        self.embedding_size = sum(self.layer_output_sizes[l] for l in descriptor_layers)
+        self._engine = None
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('MACResNet runs on an MI355X (HIP) device only: call .cuda() first (no CPU fallback).')
+        if self._engine is None:
+            self._engine = MACResNetEngine(self, dev)
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, x, eps=1e-8):
+        eng = self.engine()
+        x = x.to(device=eng.device, dtype=torch.float32)
+        assert x.shape[2] == x.shape[3], 'square inputs (the reference feeds 256x256 crops)'
+        return eng.embed_packed(ops.pack_embed_input(x, False, self.input_mean, self.input_std), eps)
+
+
+def macresnet_encoder(model='resnet50', pretrained=True, progress=True, batch_norm=True, desc_layers=[2, 3]):
+    """classification.py:111-121.  No network here: `pretrained=True` is rejected."""
+    if model != 'resnet50':
+        raise NotImplementedError(f'MACResNet not implemented for {model}')
+    if pretrained:
+        raise RuntimeError('pretrained ResNet weights cannot be downloaded here; use pretrained=False and load_state_dict')
+    return MACResNet(_ResNetSource((3, 4, 6, 3), nn.BatchNorm2d if batch_norm else nn.Identity), desc_layers)

@@ -119,7 +119,8 @@ class Classifier:
         eng = self.encoder.engine()
         for i in range(0, len(images), self.batch_size):
             batch = images[i:i + self.batch_size].to(device=self.device)
-            packed = ops.pack_embed_input(batch, True, TANH_MEAN, TANH_STD)  # scale_to_tanh + normalise fused
+            packed = ops.pack_embed_input(batch, True, getattr(self.encoder, 'input_mean', TANH_MEAN),
+                                          getattr(self.encoder, 'input_std', TANH_STD))  # scale_to_tanh + the encoder's own normalisation, fused
             emb = eng.embed_packed(packed)
             if return_embedding:
                 embs.append(emb.to(device=self.emb_device))
@@ -216,7 +217,8 @@ class BatchedPipeline:
         n = len(images)
         crops = torch.empty((n * dpi, size, size, 8), dtype=torch.bfloat16, device=eng.device)
         for i, img in enumerate(images):
-            ops.crop_resize(img, boxes[i], size, mode=1, mean=TANH_MEAN, std=TANH_STD, count=conf_count[i:i + 1],
+            ops.crop_resize(img, boxes[i], size, mode=1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
+                            std=getattr(self.classifier.encoder, 'input_std', TANH_STD), count=conf_count[i:i + 1],
                             out=crops[i * dpi:(i + 1) * dpi])
         # One host sync: the embedder only runs over the valid crops (compaction = a gather of row indices)
         counts = conf_count.tolist()

@@ -305,3 +305,41 @@ def test_head_atlas_equals_per_level(cuda, gln_model, hw):
     for a, b in zip(cls_a + reg_a, cls_l + reg_l):
         assert a.shape == b.shape
         assert (a - b).abs().max() <= 0.02 * b.abs().max() + 1e-3, ((a - b).abs().max(), b.abs().max())
+
+
+@pytest.mark.parametrize('batch_norm,desc_layers', [(True, [2, 3]), (False, [1, 2, 4])])
+def test_macresnet_parity(cuda, batch_norm, desc_layers):
+    """Optional ResNet-50 MAC encoder (classification.py:53-85,111-121) against the fp32 oracle; state-dict keys follow
+    the reference's Sequential nesting."""
+    from cvpce_amd.models import classification as C
+    from cvpce_amd import production, synthetic
+    from oracle import macresnet as om
+    torch.manual_seed(3)
+    m = C.macresnet_encoder(pretrained=False, batch_norm=batch_norm, desc_layers=desc_layers)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.4, 0.8); mod.bias.data.normal_(0, 0.1)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert m.embedding_size == sum(C.MACResNet.layer_output_sizes[l] for l in desc_layers)
+    keys = set(sd)
+    assert 'blocks.0.0.0.weight' in keys and 'blocks.0.1.0.conv1.weight' in keys and 'blocks.0.1.0.downsample.0.weight' in keys
+    assert ('blocks.0.0.1.running_mean' in keys) == batch_norm
+    if desc_layers == [2, 3]:
+        assert 'blocks.1.0.5.conv3.weight' in keys and not any(k.startswith('blocks.2') for k in keys)    # layer3 has 6 blocks; layer4 unused
+    x = torch.rand(5, 3, 256, 256, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    ref = om.macresnet_forward(x, sd, desc_layers)
+    m2 = C.macresnet_encoder(pretrained=False, batch_norm=batch_norm, desc_layers=desc_layers)
+    m2.load_state_dict(sd)
+    got = m2.to(cuda)(x.to(cuda)).cpu()
+    assert got.shape == ref.shape == (5, m.embedding_size)
+    assert torch.allclose(got.norm(dim=1), torch.ones(5), atol=1e-5)
+    assert F.cosine_similarity(got, ref, dim=1).min() > 0.999, F.cosine_similarity(got, ref, dim=1)
+    # through the Classifier: images in [0,1] are scaled to [-1,1] and NOT normalised further for this encoder
+    gal = synthetic.gallery_images(8, seed=9)
+    clf = production.Classifier(m2, synthetic.TensorGallery(gal), device=cuda, emb_device=cuda, batch_size=4, match_dtype=torch.float32)
+    labels, emb = clf.classify(((gal[:3] + 1) / 2).to(cuda), return_embedding=True)
+    assert [l[0] for l in labels] == ['sku_00000', 'sku_00001', 'sku_00002']
+    assert F.cosine_similarity(emb.cpu(), om.macresnet_forward(gal[:3], sd, desc_layers), dim=1).min() > 0.999
+    with pytest.raises(RuntimeError):
+        C.macresnet_encoder(pretrained=True)
