@@ -33,6 +33,7 @@ def parse():
     ap.add_argument('--match-dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-peaks', action='store_true', help='skip the measured-peak microbenchmarks (library GEMM, device copy)')
     return ap.parse_args()
 
 
@@ -70,6 +71,39 @@ def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
             'sample': f'oracle (fp32 torch CPU restatement): detector {n_img} images {image_size}x{image_size} at {t_det:.2f} s/image + '
                       f'crop+embed {n_crop} crops at {t_embed * 1e3:.0f} ms/crop + literal matcher {n_batches} x 32 queries x '
                       f'{len(gallery_emb)} gallery {t_match:.2f} s; extrapolated to P={dpi} proposals/image'}
+
+
+def measured_peaks(dev):
+    """the nominal gfx950 peaks re-measured on this box, as calibration beside the nominal figures --
+    a bf16 library GEMM (torch.matmul -> hipBLASLt; 8192^3, under the same power limit as the kernels) and a device-to-device
+    copy of 2 GiB (read + write bytes / time)."""
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        a @ b
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        a @ b
+    e1.record(); torch.cuda.synchronize()
+    gemm = 20 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    src = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    copy = 5 * 2 * (2 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return {'library_gemm_bf16_tflops': round(gemm, 1), 'device_copy_gbs': round(copy, 1),
+            'nominal': {'mfma_bf16_dense_tflops': MFMA_BF16_DENSE_PEAK_TFLOPS, 'hbm_gbs': 8000.0}}
+
+
+# algorithmic work per stage and image (SURVEY.md 8d): detector 298.4 GFLOP at 800x800, embed 40.09 GFLOP per crop,
+# match 2 P G D
+def stage_gflop(stage, n_img, proposals, gallery):
+    return {'detect': 298.4 * n_img, 'crop': 0.0, 'embed': 40.09 * proposals * n_img,
+            'match': 2.0 * proposals * n_img * gallery * 1024 / 1e9}[stage]
 
 
 def main():
@@ -129,6 +163,17 @@ def main():
             pipe.run(images)
         summ = ops.PROFILE.summary()
         ops.PROFILE = None
+        stage_events = []                 # a separate pass: the per-launch events above slow the 140 small detector launches
+        for _ in range(args.steps):
+            pipe.run(images, stage_events)
+        torch.cuda.synchronize()
+        stages = {}
+        for nm in ('detect', 'crop', 'embed', 'match'):
+            ms = sum(a.elapsed_time(b) for n_, a, b in stage_events if n_ == nm) / args.steps
+            gf = stage_gflop(nm, len(images), proposals, args.gallery)
+            stages[nm] = {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1),
+                          'tflops': round(gf / ms, 1) if ms > 0 else None,
+                          'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None}
         name, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
         # HBM bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the figure measured
@@ -146,9 +191,11 @@ def main():
                     'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/)',
                     'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
                     'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4),
+                    'stages': stages,
                     'all_conv_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                              'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}}
 
+    peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
@@ -170,6 +217,8 @@ def main():
         }
         if roofline is not None:
             line['roofline'] = roofline
+        if peaks is not None:
+            line['measured_peaks'] = peaks
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line), flush=True)

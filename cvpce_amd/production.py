@@ -204,16 +204,26 @@ class BatchedPipeline:
         self.confidence_threshold = confidence_threshold
 
     @torch.no_grad()
-    def run(self, images):
+    def run(self, images, stage_events=None):
         """images: list of (3,H,W) f32 cuda tensors -> dict of device tensors:
-        boxes (N,dpi,4), scores (N,dpi), count (N,) = #scores > confidence, indices (N,dpi,k) (-1 beyond count)."""
+        boxes (N,dpi,4), scores (N,dpi), count (N,) = #scores > confidence, indices (N,dpi,k) (-1 beyond count).
+        stage_events: optional list that receives (stage name, start event, end event) for detect / crop / embed / match."""
+        def mark():
+            if stage_events is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+
         det = self.detector
         eng = det.engine()
         emb_eng = self.classifier.encoder.engine()
         dpi = det.detections_per_img
         size = datautils.CLASSIFICATION_IMAGE_SIZE
+        t0 = mark()
         boxes, scores, labels, count, conf_count, gauss = eng.detect(images, det.num_classes, dpi,
                                                                      self.confidence_threshold)
+        t1 = mark()
         n = len(images)
         crops = torch.empty((n * dpi, size, size, 8), dtype=torch.bfloat16, device=eng.device)
         for i, img in enumerate(images):
@@ -228,8 +238,13 @@ class BatchedPipeline:
         else:
             sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
             valid = crops.index_select(0, sel)
+        t2 = mark()
         emb = emb_eng.embed_packed(valid)
+        t3 = mark()
         idx = self.classifier.match(emb)
+        t4 = mark()
+        if stage_events is not None:
+            stage_events += [('detect', t0, t1), ('crop', t1, t2), ('embed', t2, t3), ('match', t3, t4)]
         k = idx.shape[1] if idx.numel() else self.classifier.k
         indices = torch.full((n * dpi, k), -1, dtype=torch.int64, device=eng.device)
         if sel is None:
