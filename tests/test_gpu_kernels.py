@@ -477,3 +477,33 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
         if pool:
             ref = F.max_pool2d(ref, 2, 2)
         assert rel_err(nchw(y), ref) < 1e-2
+
+
+def test_conv3x3_atlas_masked(cuda):
+    """cvpce_conv3x3_halo_masked: two maps packed side by side with a one-pixel zero gap == the conv applied to each map
+    separately; gap pixels of the output are exactly zero (so the output is again a valid atlas)."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(3, 21, 30, 128, generator=g).to(BF)
+    b = torch.randn(3, 9, 14, 128, generator=g).to(BF)
+    wgt = torch.randn(256, 128, 3, 3, generator=g) / math.sqrt(9 * 128)
+    bias = torch.randn(256, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
+    atlas = torch.zeros(3, 21, 45, 128, dtype=BF)
+    atlas[:, :, :30] = a
+    atlas[:, 5:14, 31:45] = b
+    mask = torch.zeros(21, 45, dtype=torch.uint8)
+    mask[:, :30] = 1
+    mask[5:14, 31:45] = 1
+    y = ops.conv3x3_atlas(atlas.to(cuda), pc, mask.to(cuda), act=1)
+    ops.HALO_RAGGED = True
+    try:
+        ya = ops.conv2d(a.to(cuda), pc, act=1)
+        yb = ops.conv2d(b.to(cuda), pc, act=1)
+    finally:
+        ops.HALO_RAGGED = False
+    assert torch.equal(y[:, :, :30], ya) and torch.equal(y[:, 5:14, 31:45], yb)
+    gap = y.float() * (1 - mask.to(cuda).float())[None, :, :, None]
+    assert float(gap.abs().max()) == 0.0
+    ref = F.relu(F.conv2d(a.float().permute(0, 3, 1, 2), r16(wgt), bias, padding=1))
+    assert rel_err(nchw(y[:, :, :30].contiguous()), ref) < 1e-2
