@@ -108,6 +108,8 @@ PROFILE = None   # set to a ConvProfile() to record
 
 
 USE_STEM_1Q = False          # A/B switch: first-generation fused stem (one 4-wave team per workgroup)
+CONV1X1_ANY_SHAPE = False    # test switch: every eligible 1x1 conv through the pointwise kernel
+USE_CONV1X1 = True           # 1x1 convs with Cin, Cout % 64 == 0 through the LDS-free pointwise GEMM kernel (A/B switch)
 USE_HALO_WIDE = True         # Cout <= 128: the 16x32-tile / 32-channel-chunk halo kernel (A/B switch)
 USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
 HALO_RAGGED = False          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
@@ -162,6 +164,17 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         if prof is not None:
             e1.record()
             prof.records.append(('conv3x3_c64_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+        return out
+    # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
+    if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
+            and (CONV1X1_ANY_SHAPE or (cin <= 256 and pc.cout >= 4 * cin)) and pc.cout % 64 == 0 and not out_f32 and not in_up_shift and not pool and act in (0, 1) and n * h * w * cin * 2 < 2 ** 32):
+        rc = lib.cvpce_conv1x1_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout, pc.stride,
+                                         ho, wo, pc.k_pad, pc.cout_pad, int(act), int(res_mode if residual is not None else 0),
+                                         hr, wr, _stream())
+        check(rc, 'cvpce_conv1x1_nhwc_bf16')
+        if prof is not None:
+            e1.record()
+            prof.records.append(('conv1x1_kernel', 2.0 * n * ho * wo * pc.cout * pc.cin, e0, e1))
         return out
     rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
                                     pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),

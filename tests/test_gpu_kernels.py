@@ -105,11 +105,13 @@ def test_conv2d_parity(cuda, case):
         ref = F.max_pool2d(ref, 2, 2)
     ring_case = name.startswith('dma') or name.startswith('pool_dma')
     ops.USE_HALO_3X3 = not ring_case          # these cases pin the LDS-ring implicit-GEMM kernels (the halo kernels have their own test)
+    ops.USE_CONV1X1 = not ring_case
     try:
         y = ops.conv2d(nhwc(xin).to(cuda), pc, act=act, out_f32=o.get('f32', False), residual=res_dev, in_up_shift=in_up,
                        pool=o.get('pool', False))
     finally:
         ops.USE_HALO_3X3 = True
+        ops.USE_CONV1X1 = True
     torch.cuda.synchronize()
     got = nchw(y)
     if name.startswith('dma') or name.startswith('pool_dma'):
@@ -507,3 +509,48 @@ def test_conv3x3_atlas_masked(cuda):
     assert float(gap.abs().max()) == 0.0
     ref = F.relu(F.conv2d(a.float().permute(0, 3, 1, 2), r16(wgt), bias, padding=1))
     assert rel_err(nchw(y[:, :, :30].contiguous()), ref) < 1e-2
+
+
+C1X1_CASES = [  # n, cin, h, w, cout, stride, res ('', 'same', 'up'), act
+    (2, 64, 40, 52, 256, 1, 'same', 1),      # layer1 conv3 + identity + ReLU
+    (2, 256, 40, 52, 64, 1, '', 1),          # layer1 conv1
+    (3, 256, 33, 47, 512, 2, '', 0),         # downsample, stride 2, odd sizes
+    (1, 1024, 13, 17, 256, 1, 'up', 0),      # FPN lateral + nearest-upsampled top-down
+    (2, 512, 7, 9, 2048, 1, 'same', 1),      # layer4 expand, ragged last pixel tile
+    (1, 2048, 5, 5, 512, 1, '', 1),          # deep K
+]
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,stride,res,act', C1X1_CASES)
+def test_conv1x1_parity(cuda, n, cin, h, w, cout, stride, res, act):
+    """Pointwise GEMM kernel against the oracle conv and against the implicit-GEMM HIP kernel on the same operands."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = r16(torch.randn(n, cin, h, w, generator=g))
+    wgt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, stride, 0, device=cuda)
+    ref = F.conv2d(x, r16(wgt), bias, stride=stride)
+    rdev = None
+    if res == 'same':
+        r = r16(torch.randn(ref.shape, generator=g)); ref = ref + r; rdev = nhwc(r).to(cuda)
+    elif res == 'up':
+        r = r16(torch.randn(n, cout, (ref.shape[2] + 1) // 2, (ref.shape[3] + 1) // 2, generator=g))
+        ref = ref + F.interpolate(r, size=ref.shape[-2:], mode='nearest'); rdev = nhwc(r).to(cuda)
+    if act:
+        ref = F.relu(ref)
+    xin = nhwc(x).to(cuda)
+    ops.PROFILE = ops.ConvProfile()
+    ops.CONV1X1_ANY_SHAPE = True
+    try:
+        y = ops.conv2d(xin, pc, act=act, residual=rdev)
+        assert ops.PROFILE.records[-1][0] == 'conv1x1_kernel'
+        ops.USE_CONV1X1 = False
+        y2 = ops.conv2d(xin, pc, act=act, residual=rdev)
+        assert ops.PROFILE.records[-1][0] != 'conv1x1_kernel'
+    finally:
+        ops.USE_CONV1X1 = True
+        ops.CONV1X1_ANY_SHAPE = False
+        ops.PROFILE = None
+    assert rel_err(nchw(y), ref) < 1e-2, rel_err(nchw(y), ref)
+    assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
