@@ -108,7 +108,8 @@ PROFILE = None   # set to a ConvProfile() to record
 
 
 USE_STEM_1Q = False          # A/B switch: first-generation fused stem (one 4-wave team per workgroup)
-CONV1X1_ANY_SHAPE = False    # test switch: every eligible 1x1 conv through the pointwise kernel
+import os as _os
+CONV1X1_ANY_SHAPE = bool(int(_os.environ.get('CVPCE_CONV1X1_ANY', '0')))   # test switch: every eligible 1x1 conv through the pointwise kernel
 USE_CONV1X1 = True           # 1x1 convs with Cin, Cout % 64 == 0 through the LDS-free pointwise GEMM kernel (A/B switch)
 USE_HALO_WIDE = True         # Cout <= 128: the 16x32-tile / 32-channel-chunk halo kernel (A/B switch)
 USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
