@@ -7,6 +7,8 @@ CPU tensors are rejected loudly.
 import ctypes
 import math
 
+import os as _os
+
 import torch
 
 from . import _lib
@@ -108,12 +110,11 @@ PROFILE = None   # set to a ConvProfile() to record
 
 
 USE_STEM_1Q = False          # A/B switch: first-generation fused stem (one 4-wave team per workgroup)
-import os as _os
 CONV1X1_ANY_SHAPE = bool(int(_os.environ.get('CVPCE_CONV1X1_ANY', '0')))   # test switch: every eligible 1x1 conv through the pointwise kernel
 USE_CONV1X1 = True           # 1x1 convs with Cin, Cout % 64 == 0 through the LDS-free pointwise GEMM kernel (A/B switch)
 USE_HALO_WIDE = True         # Cout <= 128: the 16x32-tile / 32-channel-chunk halo kernel (A/B switch)
 USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
-HALO_RAGGED = False          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
+HALO_RAGGED = bool(int(_os.environ.get('CVPCE_HALO_RAGGED', '0')))          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
 USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
 USE_RESIDENT_C64 = False     # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel (the wide halo kernel is 8 % faster on conv2_1)
 FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
@@ -141,7 +142,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
                 and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
     halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
             and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
-            and act in (0, 1) and pc.cout % 8 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0))   # (ragged tiles are supported by the kernel but do not pay on the detector's 100x100 / 50x50 maps); the choice never depends on the batch size: a crop's embedding must not change with the crops it is batched with
+            and act in (0, 1) and pc.cout % 8 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0) or min(h, w) >= 48)   # ragged (masked) tiles pay from about 50x50 up (detector: 200x200 -1/3, 100x100 -1/3, 50x50 -5 %, 25x25 +20 %); the choice never depends on the batch size: a crop's embedding must not change with the crops it is batched with
             and n * h * w * pc.cin_pad * 2 < 2 ** 32)
     prof = PROFILE
     if prof is not None:
