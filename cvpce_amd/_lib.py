@@ -29,6 +29,7 @@ _ip = c_void_p
 
 SIGNATURES = {
     'cvpce_conv2d_nhwc_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 21 + [_vp]),
+    'cvpce_set_persistent_workgroups': (c_int, [c_int]),
     'cvpce_conv1x1_nhwc_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 14 + [_vp]),
     'cvpce_vgg_stem_fused': (c_int, [_vp, c_int, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp]),
     'cvpce_vgg_stem_fused_1q': (c_int, [_vp, c_int, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp]),

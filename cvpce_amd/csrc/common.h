@@ -57,6 +57,10 @@ __device__ __forceinline__ float quad_max_nonneg(float x) {
     return __int_as_float(v);
 }
 
+// number of workgroups the persistent kernels launch at most (= the CUs their stream may use: 256, or fewer under a CU mask);
+// set by cvpce_set_persistent_workgroups (elementwise.hip)
+extern int g_cvpce_persistent_wgs;
+
 static inline int cvpce_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CVPCE_OK : CVPCE_ERR_LAUNCH;

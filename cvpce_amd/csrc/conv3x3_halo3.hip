@@ -337,7 +337,7 @@ static int launch_halo3(Halo3Args a, hipStream_t stream) {
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
     hipLaunchKernelGGL((conv3x3_halo3_kernel<POOL>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }

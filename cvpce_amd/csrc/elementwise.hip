@@ -138,3 +138,11 @@ extern "C" int cvpce_l2_normalize_f32(const float* in, float* out, void* out_bf1
                        (bf16_t*)out_bf16, B, D, eps);
     return cvpce_check_launch();
 }
+
+int g_cvpce_persistent_wgs = 256;
+
+extern "C" int cvpce_set_persistent_workgroups(int n) {
+    if (n < 1 || n > 256) return CVPCE_ERR_ARG;
+    g_cvpce_persistent_wgs = n;
+    return CVPCE_OK;
+}

@@ -317,7 +317,7 @@ extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const v
         attr_set = true;
     }
     const int pairs = (a.ntiles + 1) / 2;
-    const int grid = pairs < 256 ? pairs : 256;       // one persistent workgroup (two teams) per CU
+    const int grid = pairs < g_cvpce_persistent_wgs ? pairs : g_cvpce_persistent_wgs;       // one persistent workgroup (two teams) per CU
     hipLaunchKernelGGL(vgg_stem2_kernel, dim3(grid), dim3(512), S2_SMEM, (hipStream_t)stream, a);
     return cvpce_check_launch();
 }

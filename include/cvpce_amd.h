@@ -91,6 +91,11 @@ int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias
 int cvpce_conv3x3_halo_ring(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                             int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
 
+/* Upper bound on the workgroups the persistent convolution kernels launch (default 256 = one per CU).  A host that
+ * runs them on a stream restricted to fewer CUs (hipExtStreamCreateWithCUMask) sets the bound to that CU count.
+ * Process-wide; 1 <= n <= 256. */
+int cvpce_set_persistent_workgroups(int n);
+
 /* nn.MaxPool2d (VGG 2x2 s2; ResNet stem 3x3 s2 p1), NHWC bf16 */
 int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
                               int Ho, int Wo, void* stream);
