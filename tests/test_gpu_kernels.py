@@ -554,3 +554,29 @@ def test_conv1x1_parity(cuda, n, cin, h, w, cout, stride, res, act):
         ops.PROFILE = None
     assert rel_err(nchw(y), ref) < 1e-2, rel_err(nchw(y), ref)
     assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
+
+
+@pytest.mark.parametrize('name,n,cin,hw,cout,pool', [('conv2_1', 256, 64, 128, 128, False), ('conv2_2', 256, 128, 128, 128, True),
+                                                     ('conv3_2', 256, 256, 64, 256, False), ('conv4_3', 256, 512, 32, 512, True),
+                                                     ('conv5_1', 256, 512, 16, 512, False)])
+def test_conv3x3_full_size_linearity(cuda, name, n, cin, hw, cout, pool):
+    """VGG layer shapes at the benchmark's batch (256 crops), checked by a size-independent property: with zero bias,
+    conv(2x) == 2 conv(x) and relu/pool commute with the factor -- exact in bf16 (a power of two) -- plus spot checks of
+    a few output pixels against the fp32 oracle."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(cin + hw)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    pc = ops.PackedConv(wgt, torch.zeros(cout), 1, 1, device=cuda)
+    x = torch.randn(n, hw, hw, cin, generator=g).to(BF).to(cuda)
+    y1 = ops.conv2d(x, pc, act=1, pool=pool)
+    y2 = ops.conv2d(x * 2, pc, act=1, pool=pool)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y1 * 2)
+    assert float(y1.float().abs().max()) > 0.5
+    # spot check: 3 images, one output row each, against F.conv2d on the same bf16-rounded operands
+    for img in (0, n // 2, n - 1):
+        xi = x[img:img + 1].float().permute(0, 3, 1, 2).cpu()
+        ref = F.relu(F.conv2d(xi, r16(wgt), padding=1))
+        if pool:
+            ref = F.max_pool2d(ref, 2, 2)
+        assert rel_err(nchw(y1[img:img + 1]), ref) < 1e-2

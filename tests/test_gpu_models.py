@@ -343,3 +343,26 @@ def test_macresnet_parity(cuda, batch_norm, desc_layers):
     assert F.cosine_similarity(emb.cpu(), om.macresnet_forward(gal[:3], sd, desc_layers), dim=1).min() > 0.999
     with pytest.raises(RuntimeError):
         C.macresnet_encoder(pretrained=True)
+
+
+def test_embedder_full_size_properties(cuda, vgg_model):
+    """BASELINE-size batch (8 images x 200 proposals = 1600 crops) through the whole embedder schedule, checked by
+    size-independent properties: (1) equivariance under a permutation of the batch, bit for bit -- every persistent
+    kernel's tile decode and the 6 x 256 + 64 batch split; (2) duplicated crops give identical rows; (3) unit norm,
+    non-negative entries (MAC of post-ReLU maps)."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import classification as C
+    enc, _ = vgg_model
+    eng = enc.engine()
+    g = torch.Generator().manual_seed(77)
+    base = torch.rand(400, 3, 256, 256, generator=g) * 2 - 1
+    x = base.repeat(4, 1, 1, 1)                       # crops i, i+400, i+800, i+1200 are identical
+    perm = torch.randperm(1600, generator=g)
+    packed = ops.pack_embed_input(x.to(cuda), False, C.TANH_MEAN, C.TANH_STD)
+    e1 = eng.embed_packed(packed)
+    e2 = eng.embed_packed(packed[perm.to(cuda)].contiguous())
+    torch.cuda.synchronize()
+    assert e1.shape == (1600, 1024)
+    assert torch.equal(e2, e1[perm.to(cuda)])
+    assert torch.equal(e1[:400], e1[400:800]) and torch.equal(e1[:400], e1[1200:])
+    assert torch.allclose(e1.norm(dim=1), torch.ones(1600, device=cuda), atol=1e-5) and float(e1.min()) >= 0.0
