@@ -366,3 +366,30 @@ def test_embedder_full_size_properties(cuda, vgg_model):
     assert torch.equal(e2, e1[perm.to(cuda)])
     assert torch.equal(e1[:400], e1[400:800]) and torch.equal(e1[:400], e1[1200:])
     assert torch.allclose(e1.norm(dim=1), torch.ones(1600, device=cuda), atol=1e-5) and float(e1.min()) >= 0.0
+
+
+def test_detector_full_size_properties(cuda, gln_model):
+    """BASELINE-size detector batch (8 x 3 x 2048 x 2048) by size-independent properties: a second run is bit-identical
+    (no atomics, no launch-order dependence -- head towers run on side streams), and reversing the batch reverses the
+    per-image results bit for bit; boxes lie inside the image, scores are sorted, counts are consistent."""
+    from cvpce_amd import synthetic
+    det, _ = gln_model
+    eng = det.engine()
+    imgs = [synthetic.shelf_image(40 + i, 2048, 2048).to(cuda) for i in range(8)]
+    a = eng.detect(imgs, 1, 200)
+    b = eng.detect(imgs, 1, 200)
+    c = eng.detect(imgs[::-1], 1, 200)
+    torch.cuda.synchronize()
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y)
+        assert torch.equal(x, z.flip(0))
+    boxes, scores, labels, count, conf, gauss = a
+    assert boxes.shape == (8, 200, 4) and gauss.shape[0] == 8
+    for i in range(8):
+        n = int(count[i])
+        assert 0 < n <= 200 and int(conf[i]) == int((scores[i, :n] > 0.5).sum())
+        s = scores[i, :n]
+        assert bool((s[:-1] >= s[1:]).all())
+        bx = boxes[i, :n]
+        assert float(bx.min()) >= 0 and float(bx[:, 2].max()) <= 2048 and float(bx[:, 3].max()) <= 2048
+        assert bool((bx[:, 2] >= bx[:, 0]).all()) and bool((bx[:, 3] >= bx[:, 1]).all())
