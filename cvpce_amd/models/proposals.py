@@ -420,9 +420,15 @@ class GLNEngine:
         strides = [(padded_hw[0] // g[0], padded_hw[1] // g[1]) for g in grids]
         logits = [c.view(n, -1) for c in cls]
         regs = [r.view(n, -1, 4) for r in reg]
-        image_hw = torch.tensor(resized, dtype=torch.int32).to(self.device)
-        ratios = torch.stack([torch.tensor(o, dtype=torch.float32) / torch.tensor(r, dtype=torch.float32)
-                              for o, r in zip(original, resized)]).to(self.device)
+        # per-batch-shape constants, cached: an H2D copy here would block the host behind the whole detector
+        key = (tuple(resized), tuple(original))
+        if getattr(self, '_pp_key', None) != key:
+            image_hw = torch.tensor(resized, dtype=torch.int32).to(self.device)
+            ratios = torch.stack([torch.tensor(o, dtype=torch.float32) / torch.tensor(r, dtype=torch.float32)
+                                  for o, r in zip(original, resized)]).to(self.device)
+            torch.cuda.current_stream().synchronize()
+            self._pp_key, self._pp_const = key, (image_hw, ratios)
+        image_hw, ratios = self._pp_const
         return ops.detect_postprocess(logits, regs, grids, strides, self.base_anchors, image_hw, ratios,
                                       self.num_anchors, num_classes, TOPK_CANDIDATES, SCORE_THRESH, NMS_THRESH,
                                       BBOX_XFORM_CLIP, detections_per_img, conf_thresh)
