@@ -83,11 +83,14 @@ class MACVGGEngine:
         self.device = device
         self.embedding_size = model.embedding_size
 
-    def embed_packed(self, x, eps=1e-8, want_bf16=False):
-        """x: (B,256,256,8) bf16, already normalised -> (B,1024) f32 unit-norm [, bf16 copy]."""
+    def embed_packed(self, x, eps=1e-8, want_bf16=False, batch=None):
+        """x: (B,256,256,8) bf16, already normalised -> (B,1024) f32 unit-norm [, bf16 copy].
+        batch: crops per pass of the kernel schedule (default MAX_EMBED_BATCH; a host that runs on fewer CUs passes that
+        CU count so that the persistent kernels' tile counts stay whole multiples of their grid)."""
         outs, outs_bf = [], []
-        for s in range(0, x.shape[0], MAX_EMBED_BATCH):
-            xb = x[s:s + MAX_EMBED_BATCH]
+        step = batch or MAX_EMBED_BATCH
+        for s in range(0, x.shape[0], step):
+            xb = x[s:s + step]
             desc = torch.empty((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)
             off = 0
             if self.stem is not None:
@@ -255,11 +258,12 @@ class MACResNetEngine:
             self.blocks.append(stages)
         self.device, self.embedding_size = device, model.embedding_size
 
-    def embed_packed(self, x, eps=1e-8):
+    def embed_packed(self, x, eps=1e-8, batch=None):
         """x: (B,S,S,8) bf16 -> (B, embedding_size) f32 unit-norm."""
         outs = []
-        for s in range(0, x.shape[0], MAX_EMBED_BATCH):
-            xb = x[s:s + MAX_EMBED_BATCH]
+        step = batch or MAX_EMBED_BATCH
+        for s in range(0, x.shape[0], step):
+            xb = x[s:s + step]
             desc = torch.empty((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)
             off = 0
             for stages in self.blocks:

@@ -203,6 +203,39 @@ class BatchedPipeline:
         self.classifier = classifier
         self.confidence_threshold = confidence_threshold
 
+    def _crop_embed_match(self, images, det_out, counts, embed_batch=None):
+        """Stages after the detector, on the current stream: RoI crops -> embeddings -> matched indices."""
+        boxes, scores, labels, count, conf_count, gauss = det_out
+        eng = self.detector.engine()
+        emb_eng = self.classifier.encoder.engine()
+        dpi = self.detector.detections_per_img
+        size = datautils.CLASSIFICATION_IMAGE_SIZE
+        n = len(images)
+        crops = torch.empty((n * dpi, size, size, 8), dtype=torch.bfloat16, device=eng.device)
+        for i, img in enumerate(images):
+            ops.crop_resize(img, boxes[i], size, mode=1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
+                            std=getattr(self.classifier.encoder, 'input_std', TANH_STD), count=conf_count[i:i + 1],
+                            out=crops[i * dpi:(i + 1) * dpi])
+        # the embedder only runs over the valid crops (compaction = a gather of row indices)
+        if sum(counts) == n * dpi:
+            valid, sel = crops, None
+        else:
+            sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
+            valid = crops.index_select(0, sel)
+        return crops, valid, sel
+
+    def _finish(self, images, det_out, counts, emb, idx, sel):
+        boxes, scores, labels, count, conf_count, gauss = det_out
+        n, dpi = len(images), self.detector.detections_per_img
+        k = idx.shape[1] if idx.numel() else self.classifier.k
+        indices = torch.full((n * dpi, k), -1, dtype=torch.int64, device=boxes.device)
+        if sel is None:
+            indices = idx
+        elif idx.numel():
+            indices.index_copy_(0, sel, idx)
+        return {'boxes': boxes, 'scores': scores, 'labels': labels, 'count': conf_count, 'det_count': count,
+                'indices': indices.view(n, dpi, k), 'gaussians': gauss, 'embeddings': emb, 'counts_host': counts}
+
     @torch.no_grad()
     def run(self, images, stage_events=None):
         """images: list of (3,H,W) f32 cuda tensors -> dict of device tensors:
@@ -216,40 +249,16 @@ class BatchedPipeline:
             return e
 
         det = self.detector
-        eng = det.engine()
-        emb_eng = self.classifier.encoder.engine()
-        dpi = det.detections_per_img
-        size = datautils.CLASSIFICATION_IMAGE_SIZE
         t0 = mark()
-        boxes, scores, labels, count, conf_count, gauss = eng.detect(images, det.num_classes, dpi,
-                                                                     self.confidence_threshold)
+        det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
         t1 = mark()
-        n = len(images)
-        crops = torch.empty((n * dpi, size, size, 8), dtype=torch.bfloat16, device=eng.device)
-        for i, img in enumerate(images):
-            ops.crop_resize(img, boxes[i], size, mode=1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
-                            std=getattr(self.classifier.encoder, 'input_std', TANH_STD), count=conf_count[i:i + 1],
-                            out=crops[i * dpi:(i + 1) * dpi])
-        # One host sync: the embedder only runs over the valid crops (compaction = a gather of row indices)
-        counts = conf_count.tolist()
-        if sum(counts) == n * dpi:
-            valid = crops
-            sel = None
-        else:
-            sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
-            valid = crops.index_select(0, sel)
+        counts = det_out[4].tolist()                  # one host sync: the confidence-prefix counts
+        crops, valid, sel = self._crop_embed_match(images, det_out, counts)
         t2 = mark()
-        emb = emb_eng.embed_packed(valid)
+        emb = self.classifier.encoder.engine().embed_packed(valid)
         t3 = mark()
         idx = self.classifier.match(emb)
         t4 = mark()
         if stage_events is not None:
             stage_events += [('detect', t0, t1), ('crop', t1, t2), ('embed', t2, t3), ('match', t3, t4)]
-        k = idx.shape[1] if idx.numel() else self.classifier.k
-        indices = torch.full((n * dpi, k), -1, dtype=torch.int64, device=eng.device)
-        if sel is None:
-            indices = idx
-        elif idx.numel():
-            indices.index_copy_(0, sel, idx)
-        return {'boxes': boxes, 'scores': scores, 'labels': labels, 'count': conf_count, 'det_count': count,
-                'indices': indices.view(n, dpi, k), 'gaussians': gauss, 'embeddings': emb, 'counts_host': counts}
+        return self._finish(images, det_out, counts, emb, idx, sel)

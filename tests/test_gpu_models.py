@@ -393,3 +393,4 @@ def test_detector_full_size_properties(cuda, gln_model):
         bx = boxes[i, :n]
         assert float(bx.min()) >= 0 and float(bx[:, 2].max()) <= 2048 and float(bx[:, 3].max()) <= 2048
         assert bool((bx[:, 2] >= bx[:, 0]).all()) and bool((bx[:, 3] >= bx[:, 1]).all())
+
