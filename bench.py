@@ -182,9 +182,9 @@ def main():
         traffic = None
         try:
             prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
-            for k, v in prof.items():
-                if name.split('<')[0] in k and name.split('<')[1].split(',')[0] in k.split('<')[1]:
-                    traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
+            v = prof.get(name)            # keyed by the names ops.ConvProfile uses (tools/summarise_profiles.py)
+            if v is not None:
+                traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
         except Exception:
             traffic = None
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define G2_A_BYTES (328 * 128)
 #define G2_NPIECE 41
 
-// Patch swizzle (same as conv3x3_halo.hip): 16-byte chunk c of patch pixel (py, px) lives at physical chunk
+// Patch swizzle: 16-byte chunk c of patch pixel (py, px) lives at physical chunk
 // c ^ g2_swz(py, px).  ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...), i.e. a
 // group mixes two K-quarters over complementary halves of the 16 pixel lanes; with the lane -> pixel maps below every
 // tap's fragment read is conflict-free at any alignment.

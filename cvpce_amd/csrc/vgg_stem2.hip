@@ -2,15 +2,23 @@
 //
 //     conv3x3(3->64)+bias+ReLU -> conv3x3(64->64)+bias+ReLU -> MaxPool2d(2,2)
 //
-// as ONE persistent kernel, second generation.  Same per-tile algorithm as vgg_stem.hip (conv1_1 on the 18x18 halo
-// patch into an LDS image, conv1_2's 36 K-steps out of LDS with resident weights, pooling in registers), but a
-// workgroup is now TWO independent 4-wave teams ("quads") that share the resident conv1_2 weights (72 KiB) and
-// own an LDS image + input staging buffer each.  One wave of each team sits on every SIMD, and the teams run out of
-// phase: while one is in its MFMA-bound conv1_2 phase the other does the VALU/LDS-bound parts (conv1_1 + its
-// epilogue, pooling, stores, input staging), which with one wave per SIMD (vgg_stem.hip) left the matrix pipe idle
-// for 40 % of every tile (profiles/r01d_ablation_stem.md).  The teams never wait for each other: team barriers are
-// LDS counters (ds_add + poll), s_barrier is used once, after the weights are resident.
+// as ONE persistent kernel.  Unfused, conv1_1 writes a 64-channel full-resolution tensor (8.4 MB per 256x256 crop, 13.4 GB
+// per 1600-crop batch) that conv1_2 reads straight back -- a quarter of the embedder's time at a few % of its FLOPs.
+// Here every workgroup keeps conv1_2's weights resident in LDS (72 KiB), walks 16x16 output tiles, and per tile
+//   1. evaluates conv1_1 on the 18x18 halo patch straight from the 3-channel input (MFMA, K = 3 rows of 16 = (kw 0..3)
+//      x (c 0..3), slot kw=3 / c=3 carry zero weights) into an LDS image [324 px][64 ch] (zero outside the image =
+//      conv1_2's zero padding),
+//   2. runs conv1_2's 9 taps x 4 K-steps of MFMAs out of LDS (no global traffic, no barrier inside the tap loop,
+//      fragments two K-steps ahead in registers),
+//   3. max-pools in registers (pixels are laid out in 2x2-quad order across lanes) and stores only the pooled 8x8x64 tile.
+// A workgroup is TWO independent 4-wave teams that share the resident weights and own an LDS image + input staging
+// buffer each.  One wave of each team sits on every SIMD, and the teams run out of phase: while one is in its MFMA-bound
+// conv1_2 phase the other does the VALU/LDS-bound parts (conv1_1 + its epilogue, pooling, stores, input staging), which
+// with one team per workgroup (the first version of this kernel) left the matrix pipe idle for 40 % of every tile
+// (profiles/r01d_ablation_stem.md).  The teams never wait for each other: team barriers are LDS counters (ds_add + poll),
+// s_barrier is used once, after the weights are resident.
 // Biases live in LDS and seed the accumulators (max(x + b) = max(x) + b), which also frees 64 VGPRs.
+// HBM traffic per crop: 0.5 MB in (NHWC4 bf16) + 2.1 MB out instead of 0.5 + 8.4 + 8.4 + 2.1 MB.
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 
@@ -43,7 +51,8 @@ struct Stem2Args {
     int tiles_x, tiles_y, ntiles;
 };
 
-// byte offset of 16-B chunk `chunk` of conv1_1-output patch pixel (py, px): see vgg_stem.hip / conv3x3_halo2.hip
+// byte offset of 16-B chunk `chunk` of conv1_1-output patch pixel (py, px): the swizzle of conv3x3_halo2.hip, which makes
+// the quad-ordered conv1_2 fragment reads (ds_read_b128 in non-contiguous 16-lane groups) conflict-free for every tap
 __device__ __forceinline__ int s2_swz0(int u) { return ((u & 3) << 1) | ((u >> 2) & 1); }
 __device__ __forceinline__ int s2_a1_off(int py, int px, int chunk) {
     return (py * S2_P1 + px) * 128 + ((chunk ^ s2_swz0(px >> 1) ^ (py & 1)) << 4);

@@ -109,14 +109,10 @@ class ConvProfile:
 PROFILE = None   # set to a ConvProfile() to record
 
 
-USE_STEM_1Q = False          # A/B switch: first-generation fused stem (one 4-wave team per workgroup)
 CONV1X1_ANY_SHAPE = bool(int(_os.environ.get('CVPCE_CONV1X1_ANY', '0')))   # test switch: every eligible 1x1 conv through the pointwise kernel
 USE_CONV1X1 = True           # 1x1 convs with Cin, Cout % 64 == 0 through the LDS-free pointwise GEMM kernel (A/B switch)
-USE_HALO_WIDE = True         # Cout <= 128: the 16x32-tile / 32-channel-chunk halo kernel (A/B switch)
-USE_HALO_RING = False        # A/B switch: first-generation halo kernel (weights through an LDS ring)
 HALO_RAGGED = bool(int(_os.environ.get('CVPCE_HALO_RAGGED', '0')))          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
 USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
-USE_RESIDENT_C64 = False     # A/B switch: Cin = 64 3x3 layers through the LDS-resident-weights kernel (the wide halo kernel is 8 % faster on conv2_1)
 FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register-staged fallback kernel
 
 
@@ -136,11 +132,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         hr, wr = residual.shape[1], residual.shape[2]
         if res_mode == 0:
             res_mode = 1 if (hr, wr) == (ho, wo) else 2
-    resident = (USE_RESIDENT_C64 and not FORCE_GENERIC_CONV and pc.cin_pad == 64 and pc.kh == 3 and pc.kw == 3
-                and pc.stride == 1 and pc.pad == 1 and not pool and not out_f32 and residual is None and not in_up_shift
-                and act in (0, 1) and h % 16 == 0 and w % 16 == 0 and pc.cout % 64 == 0 and pc.cout <= 256
-                and n * h * w >= 65536 and n * h * w * 128 < 2 ** 32)
-    halo = (USE_HALO_3X3 and not resident and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
+    halo = (USE_HALO_3X3 and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3
             and pc.stride == 1 and pc.pad == 1 and not out_f32 and residual is None and not in_up_shift
             and act in (0, 1) and pc.cout % 8 == 0 and pc.cout > 64 and (HALO_RAGGED or (h % 16 == 0 and w % 16 == 0) or min(h, w) >= 48)   # ragged (masked) tiles pay from about 50x50 up (detector: 200x200 -1/3, 100x100 -1/3, 50x50 -5 %, 25x25 +20 %); the choice never depends on the batch size: a crop's embedding must not change with the crops it is batched with
             and n * h * w * pc.cin_pad * 2 < 2 ** 32)
@@ -149,23 +141,14 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if halo:
-        wide = USE_HALO_WIDE and not USE_HALO_RING and pc.cout <= 128
-        fn = lib.cvpce_conv3x3_halo_ring if USE_HALO_RING else (lib.cvpce_conv3x3_halo_wide if wide else lib.cvpce_conv3x3_halo)
-        rc = fn(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
-                pc.cout_pad, int(act), int(pool), _stream())
+        # (Cout <= 128 is forwarded to the wide-tile kernel, conv3x3_halo3.hip, inside the library)
+        rc = lib.cvpce_conv3x3_halo(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
+                                    pc.cout_pad, int(act), int(pool), _stream())
         check(rc, 'cvpce_conv3x3_halo')
         if prof is not None:
             e1.record()
-            prof.records.append(('conv3x3_halo3_kernel' if wide else ('conv3x3_halo_kernel' if USE_HALO_RING else 'conv3x3_halo2_kernel') ,
+            prof.records.append(('conv3x3_halo3_kernel' if pc.cout <= 128 else 'conv3x3_halo2_kernel',
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
-        return out
-    if resident:
-        rc = lib.cvpce_conv3x3_c64_resident(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, pc.cout, pc.k_pad,
-                                            int(act), _stream())
-        check(rc, 'cvpce_conv3x3_c64_resident')
-        if prof is not None:
-            e1.record()
-            prof.records.append(('conv3x3_c64_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
         return out
     # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
     if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
@@ -238,11 +221,11 @@ def vgg_stem(x, ps):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib.cvpce_vgg_stem_fused_1q if USE_STEM_1Q else lib.cvpce_vgg_stem_fused
-    check(fn(_p(x), c, _p(ps.w1), _p(ps.b1), _p(ps.w2), _p(ps.b2), _p(out), n, h, w, _stream()), 'cvpce_vgg_stem_fused')
+    check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(ps.w1), _p(ps.b1), _p(ps.w2), _p(ps.b2), _p(out), n, h, w, _stream()),
+          'cvpce_vgg_stem_fused')
     if prof is not None:
         e1.record()
-        prof.records.append(('vgg_stem_kernel' if USE_STEM_1Q else 'vgg_stem2_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
+        prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
     return out
 
 

@@ -59,15 +59,6 @@ int cvpce_conv1x1_nhwc_bf16(const void* in, const void* wgt, const float* bias, 
  * (slots kw = 3 and c = 3 zero); w2: bf16 [9][64][64] = (tap, cout, cin); out: [N][H/2][W/2][64] bf16. */
 int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
                          const float* b2, void* out, int N, int H, int W, void* stream);
-/* Same contract, first-generation kernel (one 4-wave team per workgroup, WG-wide barriers); kept for A/B. */
-int cvpce_vgg_stem_fused_1q(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
-                            const float* b2, void* out, int N, int H, int W, void* stream);
-
-/* 3x3 / stride 1 / pad 1 convolution with Cin = 64 whose weights stay resident in LDS (VGG16 conv2_1): same
- * operands, weight layout ([Cout_pad][576], k = (kh*3+kw)*64 + ci) and numerics as cvpce_conv2d_nhwc_bf16; H, W
- * multiples of 16, Cout a multiple of 64 (<= 256); relu = 0/1.  out: [N][H][W][Cout] bf16. */
-int cvpce_conv3x3_c64_resident(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
-                               int Cout, int K_pad, int relu, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with Cin % 64 == 0 and the input halo patch resident in LDS (VGG16 conv2_2 ..
  * conv5_3, RetinaNet head / FPN 3x3s): same operands, weight layout and numerics as cvpce_conv2d_nhwc_bf16; any H, W
@@ -87,9 +78,6 @@ int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, 
  * zero padding) and one launch replaces one launch per level. */
 int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out,
                               int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu, void* stream);
-/* Same contract, first-generation kernel (weights through an LDS ring, one barrier per K-step); kept for A/B. */
-int cvpce_conv3x3_halo_ring(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
-                            int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
 
 /* Upper bound on the workgroups the persistent convolution kernels launch (default 256 = one per CU).  A host that
  * runs them on a stream restricted to fewer CUs (hipExtStreamCreateWithCUMask) sets the bound to that CU count.

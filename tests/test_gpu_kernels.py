@@ -353,16 +353,8 @@ def test_match_ties_lowest_index(cuda):
     assert idx.equal(torch.arange(5).expand(3, 5))
 
 
-@pytest.fixture(params=[False, True], ids=['teams', '1q'])
-def stem_variant(request):
-    from cvpce_amd import ops
-    ops.USE_STEM_1Q = request.param
-    yield request.param
-    ops.USE_STEM_1Q = False
-
-
 @pytest.mark.parametrize('n,h,w', [(2, 32, 48), (1, 256, 256), (3, 16, 16), (1, 16, 32), (37, 64, 64)])
-def test_vgg_stem_fused_parity(cuda, n, h, w, stem_variant):
+def test_vgg_stem_fused_parity(cuda, n, h, w):
     """Fused conv1_1+ReLU+conv1_2+ReLU+pool kernel against the oracle ops on the same bf16-rounded operands
     (conv1_1's output is rounded to bf16 before conv1_2, exactly like the unfused schedule stores it)."""
     from cvpce_amd import ops
@@ -397,36 +389,6 @@ def test_vgg_stem_rejects_bad_shapes(cuda):
         ops.vgg_stem(torch.zeros(1, 24, 16, 8, dtype=BF, device=cuda), ps)     # H not a multiple of 16
 
 
-@pytest.mark.parametrize('n,h,w,cout', [(4, 128, 128, 128), (9, 96, 112, 64), (5, 128, 128, 192)])
-def test_conv3x3_c64_resident_parity(cuda, n, h, w, cout):
-    """LDS-resident-weights kernel (VGG conv2_1 shape) against the oracle conv and bit-for-bit against the generic HIP kernel."""
-    from cvpce_amd import ops
-    g = torch.Generator().manual_seed(cout + h)
-    x = r16(torch.randn(n, 64, h, w, generator=g))
-    wgt = torch.randn(cout, 64, 3, 3, generator=g) / 24.0
-    bias = torch.randn(cout, generator=g) * 0.1
-    pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
-    ref = F.relu(F.conv2d(x, r16(wgt), bias, padding=1))
-    xin = nhwc(x).to(cuda)
-    ops.USE_RESIDENT_C64 = True           # (not the default dispatch any more: the wide halo kernel is faster on conv2_1)
-    ops.PROFILE = ops.ConvProfile()
-    try:
-        y = ops.conv2d(xin, pc, act=1)
-        assert ops.PROFILE.records[-1][0] == 'conv3x3_c64_kernel'
-        y3 = ops.conv2d(xin, pc, act=0)       # no ReLU
-    finally:
-        ops.USE_RESIDENT_C64 = False
-        ops.PROFILE = None
-    assert rel_err(nchw(y), ref) < 1e-2
-    ops.USE_HALO_3X3 = False
-    try:
-        y2 = ops.conv2d(xin, pc, act=1)
-    finally:
-        ops.USE_HALO_3X3 = True
-    assert (y.float() - y2.float()).abs().max() <= 2 ** -7 * y2.float().abs().max()
-    assert rel_err(nchw(y3), F.conv2d(x, r16(wgt), bias, padding=1)) < 1e-2
-
-
 HALO_CASES = [  # n, cin, h, w, cout, pool
     (4, 128, 128, 128, 128, True),     # VGG conv2_2 shape (TC = 128, pooled)
     (16, 128, 64, 64, 256, False),     # conv3_1
@@ -444,11 +406,10 @@ HALO_CASES = [  # n, cin, h, w, cout, pool
 ]
 
 
-@pytest.mark.parametrize('ring', [False, True, 'narrow'])
 @pytest.mark.parametrize('n,cin,h,w,cout,pool', HALO_CASES)
-def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
-    """Halo-patch kernels (register-weights and LDS-ring generation) against the implicit-GEMM HIP kernel on the same
-    inputs (and, for the small cases, the oracle)."""
+def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool):
+    """Halo-patch kernels (16x16 tiles for Cout > 128, 16x32 tiles below) against the implicit-GEMM HIP kernel on the
+    same inputs (and, for the small cases, the oracle)."""
     from cvpce_amd import ops
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn(n, h, w, cin, generator=g).to(BF)
@@ -457,8 +418,6 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
     pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
     xin = x.to(cuda)
     ops.HALO_RAGGED = True
-    ops.USE_HALO_RING = ring is True
-    ops.USE_HALO_WIDE = ring is False      # 'narrow': the 16x16-tile kernel also for Cout <= 128
     ops.PROFILE = ops.ConvProfile()
     try:
         y = ops.conv2d(xin, pc, act=1, pool=pool)
@@ -468,8 +427,6 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool, ring):
     finally:
         ops.USE_HALO_3X3 = True
         ops.HALO_RAGGED = False
-        ops.USE_HALO_RING = False
-        ops.USE_HALO_WIDE = True
         ops.PROFILE = None
     torch.cuda.synchronize()
     assert y.shape == y2.shape

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: build side libraries with compile-time ablation flags (-DCVPCE_DBG=<flags>) of ONE kernel source
-# usage: ablate.sh <source-stem, e.g. conv_igemm | vgg_stem | conv3x3_halo2> flags...
+# usage: ablate.sh <source-stem, e.g. conv_igemm | vgg_stem2 | conv3x3_halo2> flags...
 #   -> cvpce_amd/libcvpce_hip_<stem>_dbg<flags>.so ; select it with CVPCE_LIB=<path>
 set -e
 cd "$(dirname "$0")/../cvpce_amd/csrc"

@@ -26,21 +26,13 @@ ap.add_argument('--layers', default=','.join(LAYERS))
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--generic', type=int, default=0)
 ap.add_argument('--dbg', type=int, default=0)
-ap.add_argument('--resident', action='store_true')
 ap.add_argument('--no-halo', action='store_true')
-ap.add_argument('--ring', action='store_true')
-ap.add_argument('--stem1q', action='store_true')
 ap.add_argument('--relu-input', action='store_true', help='post-ReLU-like input (half zeros, non-negative) instead of N(0,1): the data regime of the real pipeline (matters: the MFMA kernels are power-limited)')
-ap.add_argument('--no-wide', action='store_true')
 ap.add_argument('--stem', action='store_true', help='time the fused VGG stem kernel on 256 crops')
 args = ap.parse_args()
 dev = torch.device('cuda')
 ops.FORCE_GENERIC_CONV = args.generic
-ops.USE_RESIDENT_C64 = args.resident
 ops.USE_HALO_3X3 = not args.no_halo
-ops.USE_HALO_RING = args.ring
-ops.USE_STEM_1Q = args.stem1q
-ops.USE_HALO_WIDE = not args.no_wide
 
 if args.stem:
     g = torch.Generator().manual_seed(0)
