@@ -1,14 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: shelf images/sec end-to-end (detect + RoI-crop + embed + match) on MI355X.
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one
-rank per GPU over RCCL).  One "step" = one pass of the whole hot path over one batch of
-`--images-per-gpu` synthetic SKU-110K-shaped shelf images per GPU (weak scaling), inputs resident in
-HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU over
+RCCL; a plain `python bench.py --gpus N` starts that launcher itself as a child process).  One "step" = one pass of the
+whole hot path over one batch of `--images-per-gpu` synthetic SKU-110K-shaped shelf images per GPU (weak scaling), inputs
+resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Workloads (`--workload`):
+  pipeline      (default) BASELINE configs[2]/[4] per-GPU shape: 8 x 3x2048x2048 -> detect -> crop -> embed -> match, G = 3200
+  detector      BASELINE configs[1]: 4 x 3x2048x2048, GLN detector only, detections_per_img = 1000
+  match-stress  BASELINE configs[3]: 200 (and 1600) queries x 10 000 gallery rows, D = 512 and 1024, bf16 distance GEMM
+Extra legs of the pipeline workload (all outside the timed region of `value`):
+  roofline      per-kernel HIP-event timing of the conv kernels + per-stage times
+  value_with_h2d  the same K steps with the images uploaded from pinned host memory on a copy stream, batch i+1 during batch i
+  parity        tests/accuracy.py on a bounded sample: HIP pipeline (bf16 defaults) vs the fp32 oracle (AP / AR300 / top-1)
+  cpu_baseline  the oracle timed on this box's host cores
+  --verify      per-image SHA-256 of (boxes, scores, matched indices) gathered to rank 0: identical for 1/2/4/8-GPU runs
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,6 +33,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
 
 
 def parse():
@@ -26,17 +41,37 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--images-per-gpu', type=int, default=8)
+    ap.add_argument('--workload', default='pipeline', choices=['pipeline', 'detector', 'match-stress'])
+    ap.add_argument('--images-per-gpu', type=int, default=None, help='default 8 (pipeline) / 4 (detector)')
     ap.add_argument('--image-size', type=int, default=2048)
     ap.add_argument('--gallery', type=int, default=3200)
-    ap.add_argument('--detections-per-img', type=int, default=200)
+    ap.add_argument('--detections-per-img', type=int, default=None, help='default 200 (pipeline, cli/eval.py:50) / 1000 (detector)')
     ap.add_argument('--match-dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-peaks', action='store_true', help='skip the measured-peak microbenchmarks (library GEMM, device copy)')
+    ap.add_argument('--no-peaks', action='store_true', help='skip the measured-peak microbenchmarks (library GEMM, device copy, bare MFMA loop)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the bounded HIP-vs-oracle accuracy sample')
+    ap.add_argument('--no-h2d', action='store_true', help='skip the H2D-inclusive leg')
     return ap.parse_args()
 
 
+def spawn_launcher(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the launcher as a CHILD process (never exec from a
+    process that may touch the GPU) and relay its output; nothing here has initialised HIP yet."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# legs shared by the workloads
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
     """The oracle (a port: plain fp32 torch CPU ops restating the reference) on a bounded sample of the same workload,
     on this box's host cores (about 10-30 s of CPU work): 3 shelf images through the detector, 64 crops through
@@ -51,6 +86,9 @@ def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
     t = time.perf_counter()
     res = [og.gln_forward([i], det_sd, detections_per_img=dpi)[0] for i in imgs]
     t_det = (time.perf_counter() - t) / n_img
+    if enc_sd is None:
+        return {'value': 1.0 / t_det, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+                'sample': f'oracle (fp32 torch CPU restatement) detector only: {n_img} images {image_size}x{image_size} at {t_det:.2f} s/image'}
     boxes = res[0]['boxes'][res[0]['scores'] > 0.5][:n_crop]
     if len(boxes) < n_crop:
         boxes = torch.tensor([[10., 10., 300., 400.]] * n_crop)
@@ -75,8 +113,10 @@ def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
 
 def measured_peaks(dev):
     """the nominal gfx950 peaks re-measured on this box, as calibration beside the nominal figures --
-    a bf16 library GEMM (torch.matmul -> hipBLASLt; 8192^3, under the same power limit as the kernels) and a device-to-device
-    copy of 2 GiB (read + write bytes / time)."""
+    a bf16 library GEMM (torch.matmul -> hipBLASLt; 8192^3, under the same power limit as the kernels), a device-to-device
+    copy of 2 GiB (read + write bytes / time), and the bare-MFMA-loop ceiling (csrc/probe.hip: register operands, random
+    data, >= 2 s per MFMA shape) that bounds what any bf16 MFMA kernel can sustain on this device."""
+    from cvpce_amd import ops
     a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
     b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
     for _ in range(3):
@@ -95,8 +135,13 @@ def measured_peaks(dev):
         dst.copy_(src)
     e1.record(); torch.cuda.synchronize()
     copy = 5 * 2 * (2 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    m32 = ops.probe_mfma_bf16(0, seconds=2.0)
+    m16 = ops.probe_mfma_bf16(1, seconds=2.0)
     return {'library_gemm_bf16_tflops': round(gemm, 1), 'device_copy_gbs': round(copy, 1),
-            'nominal': {'mfma_bf16_dense_tflops': MFMA_BF16_DENSE_PEAK_TFLOPS, 'hbm_gbs': 8000.0}}
+            'bare_mfma_loop_tflops': {'32x32x16': round(m32, 1), '16x16x32': round(m16, 1),
+                                      'note': 'register operands, random data, one wave per SIMD, >= 2 s back to back (csrc/probe.hip)'},
+            'nominal': {'mfma_bf16_dense_tflops': MFMA_BF16_DENSE_PEAK_TFLOPS, 'hbm_gbs': HBM_PEAK_GBS}}
 
 
 # algorithmic work per stage and image: detector 298.4 GFLOP at 800x800, embed 40.09 GFLOP per crop,
@@ -106,17 +151,95 @@ def stage_gflop(stage, n_img, proposals, gallery):
             'match': 2.0 * proposals * n_img * gallery * 1024 / 1e9}[stage]
 
 
-def main():
-    args = parse()
-    from cvpce_amd import dist as cdist
-    rank, local_rank, world = cdist.init()
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
-    torch.cuda.set_device(dev)
-    from cvpce_amd import ops, production, synthetic
+def conv_roofline(summ, stages=None):
+    """`roofline` object from an ops.ConvProfile summary: the dominant kernel against the dense bf16 MFMA peak."""
+    name, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
+    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    # HBM bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the figure measured
+    # by the same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (two passes, gfx950 FETCH x2
+    # correction) and committed under profiles/; null if no profile covers the kernel
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+        v = prof.get(name)            # keyed by the names ops.ConvProfile uses (tools/summarise_profiles.py)
+        if v is not None:
+            traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
+    except Exception:
+        traffic = None
+    out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/)',
+           'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
+           'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4)}
+    if stages is not None:
+        out['stages'] = stages
+    out['all_conv_kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                                   'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+    return out
 
-    dpi = args.detections_per_img
+
+def image_digest(out, i):
+    """SHA-256 over everything the path returns for image i of a BatchedPipeline result (bit-level identity check)."""
+    c, dc = int(out['counts_host'][i]), int(out['det_count'][i])
+    h = hashlib.sha256()
+    for t in (out['boxes'][i, :dc], out['scores'][i, :dc], out['labels'][i, :dc], out['indices'][i, :c]):
+        h.update(t.contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def gather_digests(local, world):
+    """{global image id: digest} from every rank -> rank 0 (the optional final gather of SURVEY.md 8e)."""
+    if world == 1:
+        return dict(local)
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, local)
+    merged = {}
+    for p in parts:
+        merged.update(dict(p))
+    return merged
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workload: full pipeline (the headline metric)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_h2d_leg(pipe, host_images, dev, steps, warmup):
+    """The same pipeline fed from pinned host memory: a copy stream uploads batch i+1 while batch i runs (the reference
+    moves every image with `.to(device)`, production.py:14).  -> seconds for `steps` steps, each including one upload."""
+    main = torch.cuda.current_stream()
+    copy_stream = torch.cuda.Stream(device=dev)
+    bufs = [[torch.empty(h.shape, dtype=h.dtype, device=dev) for h in host_images] for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(b):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(free[b])            # the step that last read this buffer has finished
+            for d, h in zip(bufs[b], host_images):
+                d.copy_(h, non_blocking=True)
+            ready[b].record(copy_stream)
+
+    def step(s):
+        b = s % 2
+        upload(1 - b)                                   # next batch: overlaps with this step's kernels
+        main.wait_event(ready[b])
+        pipe.run(bufs[b])
+        free[b].record(main)
+
+    upload(0)
+    for s in range(warmup):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        step(s)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def run_pipeline(args, rank, local_rank, world, dev):
+    from cvpce_amd import dist as cdist, ops, production, synthetic
+    ipg = args.images_per_gpu or 8
+    dpi = args.detections_per_img or 200
     det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
     enc = synthetic.synthetic_macvgg(seed=1)
     det_sd = {k: v.clone() for k, v in det.state_dict().items()} if rank == 0 else None
@@ -138,8 +261,11 @@ def main():
                                                device=dev, emb_device=dev, k=1, match_dtype=mdt)
     pipe = production.BatchedPipeline(det, clf, 0.5)
 
-    images = [synthetic.shelf_image(1000 * rank + i, args.image_size, args.image_size).to(dev)
-              for i in range(args.images_per_gpu)]
+    # images are identified by their GLOBAL index in the job's batch of world * ipg images (contiguous blocks per rank,
+    # cvpce_amd.dist.shard_images): image g is the same tensor whatever the world size
+    ids = cdist.shard_images(world * ipg, rank, world)
+    host_images = [synthetic.shelf_image(g, args.image_size, args.image_size) for g in ids]
+    images = [h.to(dev) for h in host_images]
     torch.cuda.synchronize()
 
     out = None
@@ -156,6 +282,23 @@ def main():
     elapsed = cdist.max_over_ranks(time.perf_counter() - t0, dev)
     proposals = float(sum(out['counts_host'])) / max(1, len(images))
 
+    verify = None
+    if args.verify:
+        merged = gather_digests([(g, image_digest(out, i)) for i, g in enumerate(ids)], world)
+        if rank == 0:
+            allh = hashlib.sha256(''.join(merged[g] for g in sorted(merged)).encode()).hexdigest()
+            verify = {'images': len(merged), 'digest': allh, 'per_image': {str(g): merged[g][:16] for g in sorted(merged)}}
+
+    h2d = None
+    if not args.no_h2d:
+        pinned = [h.pin_memory() for h in host_images]
+        cdist.barrier()
+        t_h2d = cdist.max_over_ranks(run_h2d_leg(pipe, pinned, dev, args.steps, max(1, args.warmup)), dev)
+        h2d = {'value_with_h2d': round(world * ipg * args.steps / t_h2d, 3), 'ms_per_step_with_h2d': round(t_h2d / args.steps * 1e3, 3),
+               'upload_mb_per_step': round(sum(h.numel() * 4 for h in host_images) / 1e6, 1),
+               'how': 'pinned host staging, uploads of batch i+1 on a copy stream during batch i (double-buffered)'}
+        del pinned
+
     roofline = None
     if not args.no_roofline and rank == 0:
         ops.PROFILE = ops.ConvProfile()
@@ -163,7 +306,7 @@ def main():
             pipe.run(images)
         summ = ops.PROFILE.summary()
         ops.PROFILE = None
-        stage_events = []                 # a separate pass: the per-launch events above slow the 140 small detector launches
+        stage_events = []                 # a separate pass: the per-launch events above slow the small detector launches
         for _ in range(args.steps):
             pipe.run(images, stage_events)
         torch.cuda.synchronize()
@@ -174,53 +317,161 @@ def main():
             stages[nm] = {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1),
                           'tflops': round(gf / ms, 1) if ms > 0 else None,
                           'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None}
-        name, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
-        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the figure measured
-        # by the same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (two passes, gfx950 FETCH x2
-        # correction) and committed under profiles/; null if no profile covers the kernel
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
-            v = prof.get(name)            # keyed by the names ops.ConvProfile uses (tools/summarise_profiles.py)
-            if v is not None:
-                traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
-        except Exception:
-            traffic = None
-        roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/)',
-                    'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
-                    'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4),
-                    'stages': stages,
-                    'all_conv_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                             'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}}
+        roofline = conv_roofline(summ, stages)
 
     peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
+    if roofline is not None and peaks is not None:
+        bare = peaks['bare_mfma_loop_tflops']
+        roofline['frac_of_bare_mfma_loop'] = round(roofline['achieved'] / max(bare['32x32x16'], bare['16x16x32']), 4)
+    parity = None
+    if not args.no_parity and rank == 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import accuracy                                           # tests/accuracy.py: the oracle as CHECKER (never timed, never shipped)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        rep = accuracy.run(n_images=4, image_size=args.image_size, galleries=(256,), dpi=dpi, queries=64, oracle_device='cpu',
+                           match_dtypes=(args.match_dtype,), images_per_batch=4)
+        parity = accuracy.summary(rep)
+        parity['sample'] = ('4 structured shelf images through the whole HIP pipeline (bench defaults) vs the whole fp32 CPU oracle; '
+                            '64 paired detections + 64 ground-truth crops vs a 256-product gallery; full-size figures (32 images, '
+                            'G = 1000 / 3200): profiles/r02_accuracy.json')
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
 
+    if rank != 0:
+        return None
+    total_images = world * ipg * args.steps
+    line = {
+        'metric': 'shelf images/sec end-to-end (detect+embed+match)',
+        'value': round(total_images / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'full production path: {ipg} shelf images/GPU of 3x{args.image_size}x{args.image_size} '
+                               f'(SKU-110K shape) -> GLN detect (800x800 internal, detections_per_img={dpi}, conf>0.5) -> RoI crop 256x256 '
+                               f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
+                   'images_per_gpu': ipg, 'global_images': world * ipg, 'proposals_per_image': proposals, 'gallery': args.gallery,
+                   'match_dtype': args.match_dtype, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
+                   'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
+                   'gallery_build_s': round(t_gallery, 3)},
+    }
+    if h2d is not None:
+        line.update(h2d)
+    for key, val in (('roofline', roofline), ('measured_peaks', peaks), ('parity', parity), ('cpu_baseline', cpu), ('verify', verify)):
+        if val is not None:
+            line[key] = val
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workload: detector only (BASELINE configs[1])
+# ---------------------------------------------------------------------------------------------------------------------
+def run_detector(args, rank, local_rank, world, dev):
+    from cvpce_amd import dist as cdist, ops, synthetic
+    ipg = args.images_per_gpu or 4
+    dpi = args.detections_per_img or 1000
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
+    det_sd = {k: v.clone() for k, v in det.state_dict().items()} if rank == 0 else None
+    det = det.to(dev)
+    eng = det.engine()
+    ids = cdist.shard_images(world * ipg, rank, world)
+    images = [synthetic.shelf_image(g, args.image_size, args.image_size).to(dev) for g in ids]
+    torch.cuda.synchronize()
+    out = None
+    for _ in range(args.warmup):
+        out = eng.detect(images, 1, dpi)
+    torch.cuda.synchronize()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.detect(images, 1, dpi)
+    torch.cuda.synchronize()
+    cdist.barrier()
+    elapsed = cdist.max_over_ranks(time.perf_counter() - t0, dev)
+    kept = float(out[3].float().mean())
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = ops.ConvProfile()
+        for _ in range(args.steps):
+            eng.detect(images, 1, dpi)
+        summ = ops.PROFILE.summary()
+        ops.PROFILE = None
+        gf = 298.4 * ipg
+        ms = elapsed / args.steps * 1e3
+        roofline = conv_roofline(summ, {'detect': {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1), 'tflops': round(gf / ms, 1),
+                                                   'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}})
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(det_sd, None, dpi, None, args.image_size)
+    if rank != 0:
+        return None
+    line = {'metric': 'shelf images/sec, GLN detector only (convs + Gaussian head + top-k/NMS)', 'value': round(world * ipg * args.steps / elapsed, 3),
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'GLN detector only: {ipg} x 3x{args.image_size}x{args.image_size} (SKU-110K shape, 800x800 internal), '
+                                   f'detections_per_img={dpi} (BASELINE configs[1])', 'images_per_gpu': ipg, 'kept_per_image': kept,
+                       'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)', 'parallelism': f'dp{world}'}}
+    if roofline is not None:
+        line['roofline'] = roofline
+    if cpu is not None:
+        line['cpu_baseline'] = cpu
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workload: distance-GEMM stress (BASELINE configs[3])
+# ---------------------------------------------------------------------------------------------------------------------
+def run_match_stress(args, rank, local_rank, world, dev):
+    from cvpce_amd import dist as cdist, ops
+    G = 10000
+    cases = []
+    g = torch.Generator().manual_seed(0)
+    iters = max(20, args.steps * 10)
+    for P, D in ((200, 512), (200, 1024), (1600, 512), (1600, 1024)):
+        gal = torch.nn.functional.normalize(torch.randn(G, D, generator=g), dim=1).to(dev).to(torch.bfloat16)
+        q = torch.nn.functional.normalize(torch.randn(P, D, generator=torch.Generator().manual_seed(1)), dim=1).to(dev).to(torch.bfloat16)
+        gn, qn = ops.row_norms(gal), ops.row_norms(q)
+        for _ in range(max(3, args.warmup)):
+            ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        flop = 2.0 * P * G * D
+        byts = (G * D + P * D) * 2 + (G + P) * 4 + P * 8          # both operands once + norms + the (P,1) int64 result
+        cases.append({'P': P, 'G': G, 'D': D, 'us_per_launch': round(us, 2), 'tflops': round(flop / us / 1e6, 1),
+                      'algorithmic_gbs': round(byts / us / 1e3, 1), 'arithmetic_intensity_flop_per_byte': round(flop / byts, 1),
+                      'bound': 'hbm' if flop / byts < MFMA_BF16_DENSE_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else 'mfma',
+                      'frac_of_hbm_peak': round(byts / us / 1e3 / HBM_PEAK_GBS, 4), 'frac_of_mfma_peak': round(flop / us / 1e6 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                      'queries_per_s': round(P / us * 1e6, 0)})
+    if rank != 0:
+        return None
+    head = cases[0]
+    return {'metric': 'distance-GEMM stress: queries/s, 200 proposals x 10 000 x 512-d gallery, bf16 MFMA with fused top-1', 'value': head['queries_per_s'],
+            'unit': 'queries/s', 'n_gpus': world, 'steps': iters, 'warmup': max(3, args.warmup), 'ms_per_step': round(head['us_per_launch'] / 1e3, 5),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'distance GEMM + fused top-1 (cvpce_match_topk), P = 200 queries (one image), G = 10 000 gallery rows, D = 512 '
+                                   '(BASELINE configs[3]); cases: P in {200, 1600} x D in {512, 1024}', 'parallelism': f'dp{world} (replicas)'},
+            'roofline': {'bound': head['bound'], 'achieved': head['algorithmic_gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': head['frac_of_hbm_peak'], 'traffic': None, 'kernel': 'match_kernel<bf16> + match_merge_kernel',
+                         'avg_launch_us': head['us_per_launch'], 'cases': cases}}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_launcher(args))
+    from cvpce_amd import dist as cdist
+    rank, local_rank, world = cdist.init()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
+    torch.cuda.set_device(dev)
+    line = {'pipeline': run_pipeline, 'detector': run_detector, 'match-stress': run_match_stress}[args.workload](args, rank, local_rank, world, dev)
     if rank == 0:
-        total_images = world * args.images_per_gpu * args.steps
-        line = {
-            'metric': 'shelf images/sec end-to-end (detect+embed+match)',
-            'value': round(total_images / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'full production path: {args.images_per_gpu} shelf images/GPU of 3x{args.image_size}x{args.image_size} '
-                                   f'(SKU-110K shape) -> GLN detect (800x800 internal, detections_per_img={dpi}, conf>0.5) -> RoI crop 256x256 '
-                                   f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
-                       'images_per_gpu': args.images_per_gpu, 'proposals_per_image': proposals, 'gallery': args.gallery,
-                       'match_dtype': args.match_dtype, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
-                       'parallelism': f'dp{world} (images sharded, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
-                       'gallery_build_s': round(t_gallery, 3)},
-        }
-        if roofline is not None:
-            line['roofline'] = roofline
-        if peaks is not None:
-            line['measured_peaks'] = peaks
-        if cpu is not None:
-            line['cpu_baseline'] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -9,6 +9,9 @@ Drop-in Python surface (same names / argument meaning as the reference):
     cvpce_amd.utils                 scale_to_tanh, scale_from_tanh, trim_module_prefix
 underneath: include/cvpce_amd.h (C ABI) -> cvpce_amd/csrc/*.hip (hand-written HIP kernels).
 """
-from . import _lib  # noqa: F401  (raises HipLibraryMissing when the HIP library is not built)
+# The HIP library is loaded by `cvpce_amd.ops` (and therefore by everything that runs a kernel: models, production, the
+# eval harnesses, the CLI): importing any of those without a built libcvpce_hip.so raises `HipLibraryMissing` -- there is
+# no CPU fallback.  The host-only modules (metrics, planograms, planogram_adapters, datautils readers, dist, defaults) never
+# call a kernel and import without it.
 
 __all__ = ['models', 'production', 'datautils', 'utils', 'ops']

@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
                 const int gl = wc * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int gg = tile_g * MT_TG + gl;
                 float d = INFINITY;
-                if (gg < a.Gn) d = 1.f - acc[mt][nt][r] / (qn * a.gn[gg]);
+                if (gg < a.Gn) {
+                    d = 1.f - acc[mt][nt][r] / (qn * a.gn[gg]);
+                    if (!(d == d)) d = INFINITY;   // a NaN distance (non-finite embedding) sorts last and still yields a valid index
+                }
                 Tl[gl * MT_TQ + ql] = d;
             }
     }

@@ -2,7 +2,6 @@
 host-side dataset readers of the eval commands (below)."""
 import torch
 
-from . import ops
 
 CLASSIFICATION_IMAGE_SIZE = 256
 
@@ -15,6 +14,7 @@ def resize_for_classification(img):
         raise RuntimeError('resize_for_classification runs on an MI355X (HIP) device only (no CPU fallback)')
     _, h, w = img.shape
     box = torch.tensor([[0.0, 0.0, float(w), float(h)]], device=img.device)
+    from . import ops          # the only kernel call in this module: the readers below are host-only
     return ops.crop_resize(img.to(torch.float32).contiguous(), box, CLASSIFICATION_IMAGE_SIZE, mode=0)[0]
 
 

@@ -4,9 +4,11 @@ scope).  Same function names, argument meaning and result dictionary as the refe
 known-answer tests (test/metrics_test.py) and by golden outputs made with the reference's own implementation
 (tests/golden/metrics.pt).
 
-Semantics kept on purpose: predictions are visited in descending confidence; each takes the highest-IoU target
-that is still unused and has IoU >= threshold (a visited-but-used target does not stop the search, an IoU below the
-threshold does); AP is the 11-point interpolated AP; AR@300 is the recall after the first 300 predictions per image.
+Semantics kept on purpose: predictions are visited in descending confidence; a prediction is a true positive when at
+least one target with IoU >= threshold is still unused, and -- like the reference's inner loop, which has no `break`
+after a match (cvpce/metrics.py:22-26) -- it then marks EVERY still-unused target at or above the threshold as used,
+not only the best one; AP is the 11-point interpolated AP; AR@300 is the recall after the first 300 predictions per
+image.
 """
 import torch
 
@@ -36,7 +38,7 @@ def check_matches(sorted_ious, indices, iou_threshold=0.5):
         cand = indices[p][ok[p]]                 # targets in descending-IoU order, cut at the threshold
         free = cand[~used[cand]]
         if free.numel():
-            used[free[0]] = True
+            used[free] = True                    # every free target above the threshold (no `break` in the reference)
             tp[p] = 1
     return tp, 1 - tp
 

@@ -364,6 +364,10 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
     assert queries.is_contiguous() and gallery.is_contiguous() and queries.shape[1] == gallery.shape[1]
     qn, d = queries.shape
     gn = gallery.shape[0]
+    k = min(int(k), gn)          # the reference's argsort[:, :k] returns min(k, G) columns (classification.py:95)
+    if k == 0 or qn == 0:
+        idx = torch.empty((qn, k), dtype=torch.int64, device=queries.device)
+        return (idx, torch.empty((qn, k), dtype=torch.float32, device=queries.device)) if return_distance else idx
     if q_norms is None:
         q_norms = row_norms(queries)
     if g_norms is None:
@@ -386,3 +390,31 @@ def pad_features(x, multiple=64):
     out = torch.zeros((x.shape[0], dp), dtype=x.dtype, device=x.device)
     out[:, :d] = x
     return out
+
+
+# ---------------------------------------------------------------------------
+# calibration
+# ---------------------------------------------------------------------------
+def probe_mfma_bf16(shape, seconds=2.0, iters=20000, workgroups=256):
+    """Sustained bare-MFMA rate of this device (TFLOP/s): `shape` 0 = 32x32x16, 1 = 16x16x32; register operands, random
+    data, one wave per SIMD, run back to back for at least `seconds` (the clock settles under the power limit)."""
+    import time
+    dev = torch.device('cuda', torch.cuda.current_device())
+    operands = torch.randn(1 << 16, device=dev).to(BF16)
+    sink = torch.empty(workgroups * 256, dtype=torch.float32, device=dev)
+    flop = workgroups * 4 * iters * 16 * (32768 if shape == 0 else 16384)
+    launch = lambda: check(lib.cvpce_probe_mfma_bf16(int(shape), int(iters), _p(operands), _p(sink), int(workgroups), _stream()), 'probe')
+    launch()
+    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 0
+    best = 0.0
+    while time.perf_counter() - t0 < seconds:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        last = 4 * flop / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        n += 4
+    return last        # the rate of the LAST group of launches: the settled clock, not the cold-start burst

@@ -41,8 +41,13 @@ class ProposalGenerator:
 
 
 class Classifier:
+    """production.py:22-74.  `match_dtype`: operand type of the distance GEMM.  float32 (default) is the reference's
+    arithmetic (classification.py:87-95 runs in fp32) on the exact-f32 matrix pipe; bfloat16 is the opt-in fast path
+    (bench.py / BatchedPipeline pass it explicitly; its top-1 agreement with the fp32 matcher on real embeddings is measured
+    by tools/accuracy.py and bounded in tests/test_gpu_accuracy.py)."""
+
     def __init__(self, encoder, sample_set, device=torch.device('cuda'), emb_device=torch.device('cuda'),
-                 batch_size=32, num_workers=8, k=1, load=None, verbose=False, match_dtype=torch.bfloat16):
+                 batch_size=32, num_workers=8, k=1, load=None, verbose=False, match_dtype=torch.float32):
         self.batch_size = batch_size
         self.num_workers = num_workers  # kept for signature parity; gallery tensors are batched in-process
         self.device = device
@@ -58,7 +63,7 @@ class Classifier:
 
     @classmethod
     def from_embedding(cls, encoder, embedding, annotations, device=torch.device('cuda'), emb_device=torch.device('cuda'),
-                       batch_size=32, k=1, match_dtype=torch.bfloat16):
+                       batch_size=32, k=1, match_dtype=torch.float32):
         """Classifier over an index that already exists (e.g. embedded sharded across GPUs and all_gathered)."""
         self = cls.__new__(cls)
         self.batch_size, self.num_workers, self.device, self.emb_device = batch_size, 0, device, emb_device

@@ -39,15 +39,22 @@ def synthetic_gln(seed=0, detections_per_img=200, tanh=False, calibrate=True):
     return calibrate_head(model) if calibrate else model
 
 
-def synthetic_macvgg(seed=1):
+def synthetic_macvgg(seed=1, batch_norm=False):
+    """Seeded MAC-VGG16; batch_norm=True is `macvgg_embedder('vgg16_bn')` (the reference default, classification.py:97) with
+    non-trivial eval-mode BatchNorm statistics."""
     state = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:
-        model = classification.macvgg_embedder('vgg16', pretrained=False)
+        model = classification.macvgg_embedder('vgg16_bn' if batch_norm else 'vgg16', pretrained=False)
         with torch.no_grad():
             for m in model.modules():
                 if isinstance(m, torch.nn.Conv2d):
                     m.bias.normal_(0, 0.05)
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1)
+                    m.running_var.uniform_(0.6, 1.6)
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.normal_(0, 0.1)
     finally:
         torch.random.set_rng_state(state)
     return model
@@ -77,3 +84,69 @@ class TensorGallery:
 
     def __getitem__(self, i):
         return self.images[i], self.annotations[i]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Structured data for the accuracy measurements (tests/accuracy.py): products with distinct low-frequency appearance pasted
+# on shelf rows.  Pure `rand` noise is the worst case for agreement statistics -- every gallery embedding is nearly the same
+# vector, so nearest-neighbour margins are at rounding level; real product photos are not like that.
+# ---------------------------------------------------------------------------------------------------------------------
+def product_images(n, seed=200, size=256):
+    """(n,3,size,size) in [0,1]: per product a base colour, a coarse random colour layout (bilinear-upsampled 4x4 and 16x16
+    grids), a few hard-edged rectangles ("labels") and a stripe pattern of random period / orientation."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty(n, 3, size, size)
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32), indexing='ij')
+    for s0 in range(0, n, 64):                      # chunks bound the temporaries
+        m = min(64, n - s0)
+        base = torch.rand(m, 3, 1, 1, generator=g)
+        coarse = F.interpolate(torch.rand(m, 3, 4, 4, generator=g), size=(size, size), mode='bilinear', align_corners=False)
+        fine = F.interpolate(torch.rand(m, 3, 16, 16, generator=g), size=(size, size), mode='bilinear', align_corners=False)
+        img = 0.45 * base + 0.35 * coarse + 0.2 * fine
+        nrect = torch.randint(2, 6, (m,), generator=g).tolist()
+        geo = torch.randint(0, 1 << 30, (m, 5, 4), generator=g)
+        col = torch.rand(m, 5, 3, generator=g)
+        for i in range(m):
+            for r in range(nrect[i]):
+                x0, y0 = int(geo[i, r, 0]) % (size - 32), int(geo[i, r, 1]) % (size - 32)
+                w, h = 24 + int(geo[i, r, 2]) % (size // 2 - 24), 24 + int(geo[i, r, 3]) % (size // 2 - 24)
+                img[i, :, y0:y0 + h, x0:x0 + w] = col[i, r][:, None, None] * 0.8 + 0.1 * fine[i, :, y0:y0 + h, x0:x0 + w]
+        period = torch.rand(m, 1, 1, generator=g) * 24 + 6
+        ang = torch.rand(m, 1, 1, generator=g) * 3.14159
+        amp = torch.rand(m, 1, 1, generator=g) * 0.15
+        stripes = torch.sin((xx[None] * torch.cos(ang) + yy[None] * torch.sin(ang)) * (6.28318 / period))
+        out[s0:s0 + m] = (img + (amp * stripes)[:, None]).clamp(0, 1)
+    return out
+
+
+def structured_shelf(seed, h, w, products, pool=None, scale=(0.45, 0.95), background=0.32):
+    """One shelf image: rows of products (rescaled copies of `products[i]`, i drawn from `pool`) standing on shelf boards.
+    -> (image (3,h,w) in [0,1], gt boxes (P,4) xyxy f32, gt product ids (P,) int64)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    pool = torch.arange(len(products)) if pool is None else torch.as_tensor(pool)
+    img = torch.full((3, h, w), background) + 0.04 * torch.rand(3, h, w, generator=g)
+    boxes, ids = [], []
+    size = products.shape[-1]
+    y = int(torch.randint(8, 40, (1,), generator=g))
+    while True:
+        row_h = int(size * (scale[0] + (scale[1] - scale[0]) * float(torch.rand(1, generator=g))))
+        if y + row_h + 14 > h:
+            break
+        x = int(torch.randint(4, 30, (1,), generator=g))
+        while True:
+            s = row_h - int(torch.randint(0, max(1, row_h // 5), (1,), generator=g))      # product height (stands on the board)
+            ws = max(16, int(s * (0.6 + 0.5 * float(torch.rand(1, generator=g)))))         # product width
+            if x + ws + 2 > w:
+                break
+            pid = int(pool[int(torch.randint(0, len(pool), (1,), generator=g))])
+            patch = F.interpolate(products[pid][None], size=(s, ws), mode='bilinear', align_corners=False)[0]
+            y0 = y + row_h - s
+            img[:, y0:y0 + s, x:x + ws] = patch
+            boxes.append([float(x), float(y0), float(x + ws), float(y0 + s)])
+            ids.append(pid)
+            x += ws + int(torch.randint(2, 12, (1,), generator=g))
+        img[:, y + row_h:y + row_h + 10, :] = 0.62                                         # the shelf board
+        y += row_h + 10 + int(torch.randint(6, 30, (1,), generator=g))
+    return img.clamp(0, 1), torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), torch.tensor(ids, dtype=torch.int64)

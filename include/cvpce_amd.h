@@ -134,6 +134,12 @@ int cvpce_match_topk(const void* queries, const void* gallery, const float* q_no
                      int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
                      long long* out_idx, float* out_dist, void* stream);
 
+/* Calibration probe (not on the hot path; bench.py `measured_peaks`): a bare bf16 MFMA loop on register operands --
+ * shape 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16; `workgroups` x 4 waves (one per SIMD) each issue
+ * iters x 16 MFMAs on 4 x 4 independent accumulators.  operands: >= 128 KiB of random bf16; sink: workgroups * 256 floats.
+ * FLOPs = workgroups * 4 * iters * 16 * F with F = 2*32*32*16 = 32768 per MFMA for shape 0 and 2*16*16*32 = 16384 for shape 1. */
+int cvpce_probe_mfma_bf16(int shape, int iters, const void* operands, float* sink, int workgroups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""End-to-end accuracy of the HIP path against the fp32 oracle at the tolerance `north_star` states ("mAP and top-1 within
+0.1 pt", "index outputs bit-exact") -- the counterpart of what the reference reports through
+/root/reference/cvpce/proposals_eval.py:19-48 (AP / AR300 of the detector), cvpce/classification_eval.py:6-56 (top-k accuracy
+of the matcher on ground-truth boxes) and cvpce/detection_eval.py:6-55.
+
+TEST INFRASTRUCTURE: this is the only place besides tests/*, `__graft_entry__.smoke()` and bench.py's checker legs where
+the oracle is imported; it lives under tests/ for that reason (a `tools/` script may not touch oracle/).  bench.py calls
+`run()` with a bounded sample for the `parity` object of its JSON line; `python tests/accuracy.py` runs the full-size
+measurement (>= 32 structured shelf images of 2048^2, galleries of 1000 and 3200 products) and writes a JSON report.
+
+What is measured (whole bf16 HIP pipeline with the PRODUCT defaults of bench.py -- bf16 activations, bf16 distance GEMM --
+against the whole fp32 oracle; nothing stage-isolated):
+
+detection (per image: HIP detections vs the oracle's detections, cvpce_amd.metrics = the reference's metric code)
+  ap50_vs_oracle / ap75_vs_oracle / ar300_vs_oracle   the oracle's detections taken as ground truth (reproduction measure;
+                                                      1.0 = every oracle box found at that IoU in confidence order)
+  frac_oracle_boxes_iou90                             fraction of oracle boxes with a HIP box at IoU > 0.9
+  pseudo_gt.{ap50_hip, ap50_oracle, delta_pt}         ground truth := the oracle's confident boxes (score > 0.5); AP of BOTH
+                                                      detectors' full outputs against it -> the "mAP delta" of north_star
+  gt.{ap50_hip, ap50_oracle, delta_pt}                against the pasted products' true boxes (near zero for random weights;
+                                                      reported for completeness)
+matching (per gallery size G and matcher dtype)
+  pairs.top1_agree / topk_agree   HIP box <-> oracle box pairs (IoU > 0.9, one to one): index the HIP pipeline matched vs the
+                                  index the oracle path (its own box -> fp32 crop -> fp32 embed -> fp32 NN) matched
+  gt_boxes.acc_hip / acc_oracle / delta_pt   classification_eval style: the true boxes cropped and matched by both paths,
+                                  top-1 accuracy against the pasted product's id, and the difference in points
+  gt_boxes.top1_agree             same crops: HIP index == oracle index
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def box_iou(a, b):
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, None, :2], b[:, :2]); rb = torch.min(a[:, None, 2:], b[:, 2:])
+    inter = (rb - lt).clamp(min=0).prod(dim=2)
+    return inter / (area_a[:, None] + area_b - inter)
+
+
+def pair_boxes(a, b, thr=0.9):
+    """One-to-one pairs (i, j) with IoU(a[i], b[j]) > thr, greedy in descending IoU."""
+    if not len(a) or not len(b):
+        return []
+    iou = box_iou(a, b)
+    cand = (iou > thr).nonzero()
+    order = torch.argsort(iou[cand[:, 0], cand[:, 1]], descending=True, stable=True)
+    used_a, used_b, out = set(), set(), []
+    for i, j in cand[order].tolist():
+        if i not in used_a and j not in used_b:
+            used_a.add(i); used_b.add(j); out.append((i, j))
+    return out
+
+
+def _ap(targets, preds, confs, thrs=(0.5, 0.75)):
+    from cvpce_amd import metrics
+    r = metrics.calculate_metrics(targets, preds, confs, iou_thresholds=thrs)
+    return {t: {'ap': float(r[t]['ap']), 'ar_300': float(r[t]['ar_300'])} for t in thrs}
+
+
+@torch.no_grad()
+def oracle_embed(x_tanh, sd, device, batch=32):
+    """(B,3,256,256) in [-1,1] -> (B,1024) through the oracle embedder, `device` = 'cpu' (the oracle of record) or 'cuda'
+    (the SAME oracle code executed by torch's fp32 GPU kernels: used only to afford large samples, cross-checked against
+    the CPU run in `run()`)."""
+    from oracle import macvgg as ovgg
+    sd_d = {k: v.to(device) for k, v in sd.items()}
+    out = []
+    for s in range(0, len(x_tanh), batch):
+        out.append(ovgg.macvgg_forward(x_tanh[s:s + batch].to(device), sd_d).cpu())
+    return torch.cat(out) if out else torch.empty(0, 1024)
+
+
+@torch.no_grad()
+def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
+        k=5, images_per_batch=8, seed=0, log=None):
+    from cvpce_amd import ops, production, synthetic, datautils
+    from oracle import gln as og, crop as ocrop, match as omatch
+    log = log or (lambda *a: None)
+    dev = torch.device('cuda:0')
+    t_start = time.perf_counter()
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
+    enc = synthetic.synthetic_macvgg(seed=1)
+    det_sd = {k_: v.clone() for k_, v in det.state_dict().items()}
+    enc_sd = {k_: v.clone() for k_, v in enc.state_dict().items()}
+    det, enc = det.to(dev), enc.to(dev)
+    galleries = tuple(sorted(int(g) for g in galleries))
+    gmax, gmin = galleries[-1], galleries[0]
+    products = synthetic.product_images(gmax, seed=200 + seed)
+    gal_tanh = products * 2 - 1                                          # gallery tensors live in [-1, 1] (datautils.py:446)
+    hip_gal = torch.cat([enc(gal_tanh[i:i + 128].to(dev)) for i in range(0, gmax, 128)])
+    log(f'[accuracy] {gmax} products, HIP gallery embedded ({time.perf_counter() - t_start:.1f} s)')
+    t = time.perf_counter()
+    orc_gal = oracle_embed(gal_tanh, enc_sd, oracle_device)
+    log(f'[accuracy] oracle gallery embedded on {oracle_device} ({time.perf_counter() - t:.1f} s)')
+    report = {'n_images': n_images, 'image_size': image_size, 'detections_per_img': dpi, 'oracle_device_embedder': oracle_device,
+              'data': 'structured shelves (cvpce_amd.synthetic.structured_shelf), seeded random-init weights'}
+    if oracle_device != 'cpu':                                           # the GPU run of the oracle code vs its CPU run
+        chk = oracle_embed(gal_tanh[:8], enc_sd, 'cpu')
+        report['oracle_cuda_vs_cpu_max_abs'] = float((chk - orc_gal[:8]).abs().max())
+    gal_cos = torch.nn.functional.cosine_similarity(hip_gal.cpu(), orc_gal, dim=1)
+    report['gallery_embedding_cosine_min'] = float(gal_cos.min())
+
+    # ---- images: HIP pipeline (product defaults) and the oracle detector ----------------------------------------------
+    shelves = [synthetic.structured_shelf(1000 * seed + i, image_size, image_size, products, pool=range(gmin)) for i in range(n_images)]
+    clf = {(g, md): production.Classifier.from_embedding(enc, hip_gal[:g], list(range(g)), device=dev, emb_device=dev, k=min(k, g),
+                                                         match_dtype=torch.bfloat16 if md == 'bf16' else torch.float32)
+           for g in galleries for md in match_dtypes}
+    first = clf[(galleries[0], match_dtypes[0])]
+    pipe = production.BatchedPipeline(det, first, 0.5)
+    hip = []
+    for s in range(0, n_images, images_per_batch):
+        imgs = [sh[0].to(dev) for sh in shelves[s:s + images_per_batch]]
+        out = pipe.run(imgs)
+        emb, off = out['embeddings'], 0
+        for i in range(len(imgs)):
+            c, dc = int(out['count'][i]), int(out['det_count'][i])
+            e = emb[off:off + c]; off += c
+            idx = {key: (c_.match(e).cpu() if c else torch.empty(0, c_.k, dtype=torch.int64)) for key, c_ in clf.items()}
+            hip.append({'boxes': out['boxes'][i, :dc].cpu(), 'scores': out['scores'][i, :dc].cpu(), 'conf': c, 'idx': idx})
+    t = time.perf_counter()
+    orc = [og.gln_forward([sh[0]], det_sd, detections_per_img=dpi)[0] for sh in shelves]
+    log(f'[accuracy] oracle detector on {n_images} images ({time.perf_counter() - t:.1f} s)')
+
+    # ---- detection -----------------------------------------------------------------------------------------------------
+    hb, hs = [h['boxes'] for h in hip], [h['scores'] for h in hip]
+    ob, os_ = [o['boxes'] for o in orc], [o['scores'] for o in orc]
+    vs = _ap(ob, hb, hs)
+    pg = [o['boxes'][o['scores'] > 0.5] for o in orc]
+    gt = [sh[1] for sh in shelves]
+    found, total, dscore, dbox = 0, 0, [], []
+    for h, o in zip(hip, orc):
+        pairs = pair_boxes(h['boxes'], o['boxes'])
+        found += len(pairs); total += len(o['boxes'])
+        if pairs:
+            i, j = torch.tensor(pairs).t()
+            dscore.append((h['scores'][i] - o['scores'][j]).abs())
+            dbox.append((h['boxes'][i] - o['boxes'][j]).abs().max(dim=1).values)
+    dscore = torch.cat(dscore) if dscore else torch.zeros(1)
+    dbox = torch.cat(dbox) if dbox else torch.zeros(1)
+    a_h, a_o = _ap(pg, hb, hs), _ap(pg, ob, os_)
+    g_h, g_o = _ap(gt, hb, hs), _ap(gt, ob, os_)
+    report['detection'] = {
+        'ap50_vs_oracle': vs[0.5]['ap'], 'ap75_vs_oracle': vs[0.75]['ap'], 'ar300_vs_oracle': vs[0.5]['ar_300'],
+        'ar300_iou75_vs_oracle': vs[0.75]['ar_300'],
+        'frac_oracle_boxes_iou90': found / max(1, total), 'oracle_boxes': total,
+        'paired_abs_score_diff_max': float(dscore.max()), 'paired_abs_score_diff_mean': float(dscore.mean()),
+        'paired_box_diff_px_max': float(dbox.max()), 'paired_box_diff_px_mean': float(dbox.mean()),
+        'count_hip': sum(len(b) for b in hb), 'count_oracle': sum(len(b) for b in ob),
+        'confident_hip': sum(h['conf'] for h in hip), 'confident_oracle': sum(len(p) for p in pg),
+        'pseudo_gt': {'ap50_hip': a_h[0.5]['ap'], 'ap50_oracle': a_o[0.5]['ap'], 'delta_pt': 100 * (a_h[0.5]['ap'] - a_o[0.5]['ap']),
+                      'ap75_hip': a_h[0.75]['ap'], 'ap75_oracle': a_o[0.75]['ap'], 'delta75_pt': 100 * (a_h[0.75]['ap'] - a_o[0.75]['ap']),
+                      'ar300_hip': a_h[0.5]['ar_300'], 'ar300_oracle': a_o[0.5]['ar_300'],
+                      'delta_ar300_pt': 100 * (a_h[0.5]['ar_300'] - a_o[0.5]['ar_300'])},
+        'gt': {'ap50_hip': g_h[0.5]['ap'], 'ap50_oracle': g_o[0.5]['ap'], 'delta_pt': 100 * (g_h[0.5]['ap'] - g_o[0.5]['ap'])}}
+
+    # ---- matching: paired detections ------------------------------------------------------------------------------------
+    gen = torch.Generator().manual_seed(77 + seed)
+    allp = []
+    for n, (h, o) in enumerate(zip(hip, orc)):
+        oc = o['boxes'][o['scores'] > 0.5]
+        for i, j in pair_boxes(h['boxes'][:h['conf']], oc):
+            lb = oc[j].to(torch.long)
+            if lb[2] > lb[0] and lb[3] > lb[1]:
+                allp.append((n, i, j))
+    sel = [allp[i] for i in torch.randperm(len(allp), generator=gen)[:queries].tolist()]
+    t = time.perf_counter()
+    crops = []
+    for n, i, j in sel:
+        oc = orc[n]['boxes'][orc[n]['scores'] > 0.5]
+        crops.append(ocrop.crop_boxes(shelves[n][0], oc[j:j + 1])[0])
+    q_orc = oracle_embed(ocrop.scale_to_tanh(torch.stack(crops)), enc_sd, oracle_device) if crops else torch.empty(0, 1024)
+    log(f'[accuracy] oracle crop+embed of {len(sel)} paired detections ({time.perf_counter() - t:.1f} s)')
+    # ---- matching: ground-truth boxes (classification_eval.py:19-42 flow) ------------------------------------------------
+    allg = [(n, b) for n, sh in enumerate(shelves) for b in range(len(sh[1]))]
+    selg = [allg[i] for i in torch.randperm(len(allg), generator=gen)[:queries].tolist()]
+    t = time.perf_counter()
+    gcrops = [ocrop.crop_boxes(shelves[n][0], shelves[n][1][b:b + 1])[0] for n, b in selg]
+    g_orc = oracle_embed(ocrop.scale_to_tanh(torch.stack(gcrops)), enc_sd, oracle_device) if gcrops else torch.empty(0, 1024)
+    log(f'[accuracy] oracle crop+embed of {len(selg)} ground-truth boxes ({time.perf_counter() - t:.1f} s)')
+    g_true = torch.tensor([int(shelves[n][2][b]) for n, b in selg])
+    # HIP side of the ground-truth crops: crop kernel (mode 0, like ProposalGenerator) + Classifier.classify's embed path
+    g_hip_emb = []
+    for n in sorted(set(n for n, _ in selg)):
+        bs = [b for m, b in selg if m == n]
+        cr = ops.crop_resize(shelves[n][0].to(dev).contiguous(), shelves[n][1][bs].to(dev), datautils.CLASSIFICATION_IMAGE_SIZE, mode=0)
+        packed = ops.pack_embed_input(cr, True, enc.input_mean, enc.input_std)
+        g_hip_emb.append((n, bs, enc.engine().embed_packed(packed)))
+    order = {(n, b): None for n, b in selg}
+    for n, bs, e in g_hip_emb:
+        for b, row in zip(bs, e):
+            order[(n, b)] = row
+    g_hip = torch.stack([order[key] for key in selg]) if selg else torch.empty(0, 1024, device=dev)
+    emb_cos = torch.nn.functional.cosine_similarity(g_hip.cpu(), g_orc, dim=1) if len(selg) else torch.ones(1)
+    report['embedding_cosine_min_gt_crops'] = float(emb_cos.min())
+    report['matching'] = {}
+    for g in galleries:
+        o_idx = omatch.nearest_neighbors(orc_gal[:g], q_orc, min(k, g)) if len(q_orc) else torch.empty(0, k, dtype=torch.int64)
+        og_idx = omatch.nearest_neighbors(orc_gal[:g], g_orc, min(k, g)) if len(g_orc) else torch.empty(0, k, dtype=torch.int64)
+        d = omatch.cosine_distance_matrix(orc_gal[:g], g_orc).sort(dim=1).values if len(g_orc) else torch.zeros(0, 2)
+        for md in match_dtypes:
+            h_idx = torch.stack([hip[n]['idx'][(g, md)][i] for n, i, j in sel]) if sel else torch.empty(0, k, dtype=torch.int64)
+            hg_idx = clf[(g, md)].match(g_hip).cpu() if len(selg) else torch.empty(0, k, dtype=torch.int64)
+            top1 = (h_idx[:, 0] == o_idx[:, 0]).float().mean().item() if len(sel) else None
+            topk = (h_idx == o_idx[:, :1]).any(dim=1).float().mean().item() if len(sel) else None
+            acc_h = (hg_idx[:, 0] == g_true).float().mean().item() if len(selg) else None
+            acc_o = (og_idx[:, 0] == g_true).float().mean().item() if len(selg) else None
+            agree = (hg_idx[:, 0] == og_idx[:, 0])
+            flips = ~agree
+            report['matching'][f'G{g}_{md}'] = {
+                'pairs': {'n': len(sel), 'top1_agree': top1, f'top{k}_contains_oracle_top1': topk},
+                'gt_boxes': {'n': len(selg), 'acc_hip': acc_h, 'acc_oracle': acc_o,
+                             'delta_pt': 100 * (acc_h - acc_o) if selg else None,
+                             'top1_agree': agree.float().mean().item() if len(selg) else None,
+                             'oracle_margin_median': float((d[:, 1] - d[:, 0]).median()) if len(selg) else None,
+                             'oracle_margin_at_flips_max': float((d[:, 1] - d[:, 0])[flips].max()) if flips.any() else 0.0}}
+    report['seconds'] = round(time.perf_counter() - t_start, 1)
+    return report
+
+
+def summary(report):
+    """The handful of figures bench.py puts into its `parity` object."""
+    d = report['detection']
+    out = {'images': report['n_images'], 'ap50_vs_oracle': round(d['ap50_vs_oracle'], 4), 'ar300_vs_oracle': round(d['ar300_vs_oracle'], 4),
+           'frac_oracle_boxes_iou90': round(d['frac_oracle_boxes_iou90'], 4),
+           'map_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_pt'], 3), 'ar300_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_ar300_pt'], 3)}
+    for key, m in report['matching'].items():
+        out[key] = {'pairs': m['pairs']['n'], 'top1_agree': None if m['pairs']['top1_agree'] is None else round(m['pairs']['top1_agree'], 4),
+                    'gt_crops': m['gt_boxes']['n'],
+                    'gt_top1_agree': None if m['gt_boxes']['top1_agree'] is None else round(m['gt_boxes']['top1_agree'], 4),
+                    'top1_acc_delta_pt': None if m['gt_boxes']['delta_pt'] is None else round(m['gt_boxes']['delta_pt'], 3)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--images', type=int, default=32)
+    ap.add_argument('--image-size', type=int, default=2048)
+    ap.add_argument('--galleries', default='1000,3200')
+    ap.add_argument('--queries', type=int, default=1024)
+    ap.add_argument('--detections-per-img', type=int, default=200)
+    ap.add_argument('--oracle-device', default='cpu', choices=['cpu', 'cuda'])
+    ap.add_argument('--out', default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rep = run(a.images, a.image_size, tuple(int(g) for g in a.galleries.split(',')), a.detections_per_img, a.queries, a.oracle_device,
+              log=lambda *x: print(*x, flush=True))
+    text = json.dumps(rep, indent=1)
+    print(text)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        open(a.out, 'w').write(text + '\n')
+
+
+if __name__ == '__main__':
+    main()

@@ -185,8 +185,31 @@ def main():
         r = ref_metrics.calculate_metrics(tg, pr, cf, iou_thresholds=(0.5, 0.75))
         rnd.append({'targets': tg, 'predictions': pr, 'confidences': cf,
                     'result': {t: {k: v for k, v in d.items() if k != 'raw'} | {'raw': d['raw']} for t, d in r.items()}})
+    # dense, mutually overlapping targets: one prediction reaches SEVERAL still-unused targets above the threshold, and
+    # the reference's inner loop (cvpce/metrics.py:22-26, no break after a match) marks every one of them as used
+    two = (torch.tensor([[0, 0, 10, 10], [0, 0, 10, 9]], dtype=torch.float),
+           torch.tensor([[0, 0, 10, 10], [0, 0, 10, 9.5]], dtype=torch.float))
+    tp2, fp2 = ref_metrics.check_matches(*ref_metrics.iou_matrices(*two))
+    assert tp2.tolist() == [1, 0]
+    dense = []
+    for n_img in (2, 4):
+        tg, pr, cf = [], [], []
+        for _ in range(n_img):
+            nt = int(torch.randint(6, 16, (1,), generator=g))
+            xy = torch.rand(nt, 2, generator=g) * 12
+            wh = torch.rand(nt, 2, generator=g) * 6 + 20
+            t = torch.cat([xy, xy + wh], 1)
+            npred = int(torch.randint(4, 24, (1,), generator=g))
+            pick = torch.randint(0, nt, (npred,), generator=g)
+            p = t[pick] + torch.randn(npred, 4, generator=g) * 1.5
+            p[:, 2:] = torch.max(p[:, 2:], p[:, :2] + 1)
+            tg.append(t); pr.append(p); cf.append(torch.rand(npred, generator=g))
+        r = ref_metrics.calculate_metrics(tg, pr, cf, iou_thresholds=(0.5, 0.75))
+        dense.append({'targets': tg, 'predictions': pr, 'confidences': cf,
+                      'result': {t: {k: v for k, v in d.items() if k != 'raw'} | {'raw': d['raw']} for t, d in r.items()}})
     torch.save({'targets': T, 'predictions': P, 'confidences': C,
-                'kat_result': {k: v for k, v in res[0.5].items()}, 'random': rnd},
+                'kat_result': {k: v for k, v in res[0.5].items()}, 'random': rnd,
+                'two_targets': {'targets': two[0], 'predictions': two[1], 'tp': tp2, 'fp': fp2}, 'dense': dense},
                os.path.join(HERE, 'metrics.pt'))
     # ---- 4. planogram graph logic (cvpce/planograms.py:12-132; needs networkx only) --------------
     sys.modules['cv2'].findHomography = None

@@ -1,7 +1,10 @@
 """The N>1 launch contract rehearsed on ONE GPU: two ranks (gloo rendezvous, both on cuda:0) run bench.py exactly as
-the driver launches it for N GPUs -- sharded gallery embed + one all_gather, images sharded, max-over-ranks timing."""
+the driver launches it for N GPUs -- sharded gallery embed + one all_gather, images sharded by global index, max-over-ranks
+timing -- and the union of their per-image results is BIT-IDENTICAL to the 1-rank run over the same global batch
+("results must be bit-identical across 1/2/4/8-GPU runs")."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -9,17 +12,40 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ['--steps', '1', '--warmup', '1', '--gallery', '96', '--image-size', '640', '--no-cpu-baseline', '--no-roofline', '--no-parity',
+          '--no-h2d', '--verify']
 
 
-def test_bench_two_ranks(cuda):
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _bench(world, images_per_gpu):
     env = dict(os.environ, CVPCE_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
-           '--images-per-gpu', '1', '--gallery', '96', '--image-size', '640', '--no-cpu-baseline', '--no-roofline']
+    tail = [os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--images-per-gpu', str(images_per_gpu)] + COMMON
+    if world == 1:
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port())] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
-    d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['unit'] == 'images/s' and d['value'] > 0
-    assert d['config']['gallery'] == 96 and d['config']['images_per_gpu'] == 1
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_bit_identical_to_one_rank(cuda):
+    two = _bench(2, 2)
+    assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['unit'] == 'images/s' and two['value'] > 0
+    assert two['config']['gallery'] == 96 and two['config']['images_per_gpu'] == 2 and two['config']['global_images'] == 4
+    one = _bench(1, 4)
+    assert one['n_gpus'] == 1 and one['config']['global_images'] == 4
+    assert two['verify']['images'] == one['verify']['images'] == 4
+    assert two['verify']['per_image'] == one['verify']['per_image']      # every image: same boxes, scores, labels, matched indices
+    assert two['verify']['digest'] == one['verify']['digest']
+    assert len(set(one['verify']['per_image'].values())) == 4            # (different images do give different results)

@@ -7,6 +7,7 @@ the output when the output is bf16).  Index outputs (top-k, NMS, nearest neighbo
 """
 import math
 import os
+import zlib
 
 import pytest
 import torch
@@ -78,7 +79,7 @@ CONV_CASES = [
 def test_conv2d_parity(cuda, case):
     from cvpce_amd import ops
     name, n, cin, h, w, cout, k, stride, pad, o = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # stable across processes (str hashes are salted)
     x = torch.randn(n, cin, h, w, generator=g)
     wgt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
     bias = torch.randn(cout, generator=g) * 0.1
@@ -229,16 +230,17 @@ def _random_head_outputs(n, grids, a, k, seed, spread=2.0, bias=-1.0):
     return cls, reg
 
 
-@pytest.mark.parametrize('dpi,seed,bias', [(1000, 0, -1.0), (200, 1, 1.0), (300, 2, -4.5)])
-def test_detect_postprocess_parity(cuda, dpi, seed, bias):
-    """K6-K8 against the oracle on identical fp32 logits: kept sets and order identical."""
+@pytest.mark.parametrize('dpi,seed,bias,k', [(1000, 0, -1.0, 1), (200, 1, 1.0, 1), (300, 2, -4.5, 1), (300, 3, -1.0, 3), (1000, 4, 0.5, 2)])
+def test_detect_postprocess_parity(cuda, dpi, seed, bias, k):
+    """K6-K8 against the oracle on identical fp32 logits: kept sets and order identical; k > 1 classes exercise the
+    per-class offsets of batched_nms and the anchor / label split of the flat candidate index."""
     from cvpce_amd import ops
     from cvpce_amd.models import proposals as P
     from oracle import gln as og
     n = 2
     padded = (800, 832)
     grids = [(100, 104), (50, 52), (25, 26), (13, 13), (7, 7)]
-    cls, reg = _random_head_outputs(n, grids, 9, 1, seed, bias=bias)
+    cls, reg = _random_head_outputs(n, grids, 9, k, seed, bias=bias)
     resized = [(800, 810), (790, 832)]
     original = [(2048, 2073), (1000, 1053)]
     anchors = og.grid_anchors(padded, grids)
@@ -250,17 +252,18 @@ def test_detect_postprocess_parity(cuda, dpi, seed, bias):
                           for o, r in zip(original, resized)])
     boxes, scores, labels, count, conf = ops.detect_postprocess(
         [c.to(cuda) for c in cls], [r.to(cuda) for r in reg], grids, strides, base.to(cuda), image_hw.to(cuda),
-        ratios.to(cuda), 9, 1, og.TOPK_CANDIDATES, og.SCORE_THRESH, og.NMS_THRESH, og.BBOX_XFORM_CLIP, dpi, 0.5)
+        ratios.to(cuda), 9, k, og.TOPK_CANDIDATES, og.SCORE_THRESH, og.NMS_THRESH, og.BBOX_XFORM_CLIP, dpi, 0.5)
     torch.cuda.synchronize()
     for i in range(n):
         # oracle with the documented tie refinement: order by logit (monotone in score), then index
-        b, s, l = og.postprocess_image([c[i][:, None] for c in cls], [r[i] for r in reg], anchors, resized[i], dpi)
+        b, s, l = og.postprocess_image([c[i].view(-1, k) for c in cls], [r[i] for r in reg], anchors, resized[i], dpi)
         b = og.resize_boxes(b, resized[i], original[i])
         c = int(count[i])
         assert c == len(b), (c, len(b))
         torch.testing.assert_close(scores[i, :c].cpu(), s, rtol=0, atol=1e-6)
         torch.testing.assert_close(boxes[i, :c].cpu(), b, rtol=1e-5, atol=2e-3)
-        assert (labels[i, :c] == 0).all()
+        assert torch.equal(labels[i, :c].cpu(), l)
+        assert k == 1 or len(set(l.tolist())) == k
         assert int(conf[i]) == int((s > 0.5).sum())
         assert (scores[i, :c - 1] >= scores[i, 1:c]).all()
 
@@ -327,7 +330,8 @@ def test_match_reference_kat_and_golden(cuda, golden_dir):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('qn,gn,d,k', [(200, 1000, 1024, 1), (37, 3200, 1024, 4), (130, 129, 512, 3), (5, 10000, 512, 1)])
+@pytest.mark.parametrize('qn,gn,d,k', [(200, 1000, 1024, 1), (37, 3200, 1024, 4), (130, 129, 512, 3), (5, 10000, 512, 1),
+                                        (200, 10000, 512, 1), (1600, 10000, 1024, 1)])   # the last two: BASELINE configs[3] (distance-GEMM stress)
 def test_match_parity(cuda, dtype, qn, gn, d, k):
     from cvpce_amd import ops
     from oracle import match as omatch
@@ -343,6 +347,27 @@ def test_match_parity(cuda, dtype, qn, gn, d, k):
     assert safe.float().mean() > 0.9
     assert idx.cpu()[safe].equal(ref_idx[safe])
     torch.testing.assert_close(dist.cpu(), ref_d.gather(1, idx.cpu()), rtol=0, atol=2e-6)
+
+
+def test_match_k_clamped_and_nan_rows(cuda):
+    """classification.py:95 `argsort[:, :k]` returns min(k, G) columns; a query with a non-finite embedding still gets valid
+    gallery indices (NaN distances sort last), so `annotations[j]` lookups never go out of range."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import classification as C
+    g = torch.Generator().manual_seed(3)
+    G = F.normalize(torch.rand(5, 64, generator=g), dim=1)
+    Q = F.normalize(torch.rand(4, 64, generator=g), dim=1)
+    idx = C.nearest_neighbors(G.to(cuda), Q.to(cuda), k=8).cpu()
+    assert idx.shape == (4, 5)
+    for row in idx.tolist():
+        assert sorted(row) == [0, 1, 2, 3, 4]
+    assert C.nearest_neighbors(G.to(cuda), torch.empty(0, 64).to(cuda), k=2).shape == (0, 2)
+    Qn = Q.clone(); Qn[1, 3] = float('nan')
+    for dt in (torch.float32, torch.bfloat16):
+        idx = ops.match_topk(Qn.to(dt).to(cuda), G.to(dt).to(cuda), 3).cpu()
+        assert int(idx.min()) >= 0 and int(idx.max()) < 5
+        assert idx[1].tolist() == [0, 1, 2]                  # all distances of the NaN row are +inf: lowest indices first
+        assert idx[[0, 2, 3]].equal(ops.match_topk(Q.to(dt).to(cuda), G.to(dt).to(cuda), 3).cpu()[[0, 2, 3]])
 
 
 def test_match_ties_lowest_index(cuda):

@@ -65,6 +65,24 @@ def test_macvgg_parity(cuda, vgg_model):
     assert (got - ref).abs().max() < 5e-3
 
 
+def test_macvgg_bn_parity(cuda):
+    """`macvgg_embedder('vgg16_bn')` -- the reference's default embedder (classification.py:97): eval-mode BatchNorm folded
+    into the packed conv weights (fused stem included) against the oracle's literal conv -> F.batch_norm -> relu chain."""
+    from cvpce_amd import synthetic
+    from oracle import macvgg as ovgg
+    m = synthetic.synthetic_macvgg(seed=2, batch_norm=True)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert 'block1.1.running_mean' in sd and 'block2.41.weight' in sd and 'block1.30.weight' in sd
+    x = torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    ref = ovgg.macvgg_forward(x, sd)
+    got = m.to(cuda)(x.to(cuda)).cpu()
+    assert got.shape == (4, 1024)
+    torch.testing.assert_close(got.norm(dim=1), torch.ones(4), rtol=0, atol=1e-5)
+    cos = F.cosine_similarity(got, ref, dim=1)
+    assert cos.min() > 0.999, cos
+    assert (got - ref).abs().max() < 5e-3
+
+
 def test_config1_plumbing_and_parity(cuda, gln_model):
     """BASELINE config 1: one 640x640 random image through gln() + ProposalGenerator."""
     from cvpce_amd import production

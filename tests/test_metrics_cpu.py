@@ -80,6 +80,22 @@ def test_against_reference_outputs(golden_dir):
                 assert torch.allclose(got[thr]['raw'][k], want['raw'][k])
 
 
+def test_one_prediction_overlapping_several_targets(golden_dir):
+    """The reference's matching loop has no `break` (cvpce/metrics.py:22-26): a matched prediction uses up EVERY free target
+    at or above the threshold.  Reference-made outputs on dense, mutually overlapping targets."""
+    g = torch.load(os.path.join(golden_dir, 'metrics.pt'), weights_only=False)
+    two = g['two_targets']
+    tp, fp = metrics.check_matches(*metrics.iou_matrices(two['targets'], two['predictions']))
+    assert tp.tolist() == two['tp'].tolist() == [1, 0] and fp.tolist() == two['fp'].tolist()
+    for case in g['dense']:
+        got = metrics.calculate_metrics(case['targets'], case['predictions'], case['confidences'], iou_thresholds=(0.5, 0.75))
+        for thr, want in case['result'].items():
+            for k in ('ap', 'ar_300', 'p', 'r', 'f', 'c'):
+                assert torch.isclose(torch.as_tensor(got[thr][k], dtype=torch.float), torch.as_tensor(want[k], dtype=torch.float)), (thr, k)
+            for k in ('p', 'r', 'f', 'c'):
+                assert torch.allclose(got[thr]['raw'][k], want['raw'][k])
+
+
 def test_edge_cases():
     empty = metrics.calculate_metrics([torch.zeros(0, 4)], [torch.zeros(0, 4)], [torch.zeros(0)])[0.5]
     assert empty['f'] == 0.0 and empty['ap'] == 0

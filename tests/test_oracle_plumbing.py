@@ -83,6 +83,30 @@ def test_macvgg_oracle():
     assert torch.isfinite(z).all() and (z == 0).all()                               # clamp(min=eps) path
 
 
+def test_macvgg_oracle_batch_norm_variant():
+    """`macvgg_embedder('vgg16_bn')` (classification.py:24-37 with batch_norm=True): cut-offs 33 / 43, conv at features index
+    i, its BatchNorm2d at i + 1; the literal eval-mode F.batch_norm path equals the same network with BN folded into the convs."""
+    from cvpce_amd import synthetic
+    sd = synthetic.synthetic_macvgg(seed=2, batch_norm=True).state_dict()
+    assert ovgg.has_batch_norm(sd) and ovgg.cutoffs(True) == (33, 43) and ovgg.cutoffs(False) == (23, 30)
+    convs = [p[0] for p in ovgg.feature_plan(True) if p[1] == 'conv']
+    assert convs == [0, 3, 7, 10, 14, 17, 20, 24, 27, 30, 34, 37, 40]
+    for i in convs:
+        blk = 'block1' if i < 33 else 'block2'
+        assert f'{blk}.{i}.weight' in sd and f'{blk}.{i + 1}.running_var' in sd
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    e = ovgg.macvgg_forward(x, sd)
+    folded, plain = {}, [p[0] for p in ovgg.feature_plan(False) if p[1] == 'conv']
+    for i, j in zip(convs, plain):
+        blk, blk2 = ('block1' if i < 33 else 'block2'), ('block1' if j < 23 else 'block2')
+        q = f'{blk}.{i + 1}'
+        s = sd[q + '.weight'] * (sd[q + '.running_var'] + ovgg.BN_EPS).rsqrt()
+        folded[f'{blk2}.{j}.weight'] = sd[f'{blk}.{i}.weight'] * s[:, None, None, None]
+        folded[f'{blk2}.{j}.bias'] = (sd[f'{blk}.{i}.bias'] - sd[q + '.running_mean']) * s + sd[q + '.bias']
+    assert torch.allclose(e, ovgg.macvgg_forward(x, folded), atol=2e-5)
+    assert torch.allclose(e.norm(dim=1), torch.ones(1), atol=1e-5)
+
+
 def test_matcher_oracle_edge_cases():
     a = F.normalize(torch.rand(10, 16, generator=torch.Generator().manual_seed(4)), dim=1)
     assert omatch.nearest_neighbors(a, a[[3, 7]], 1)[:, 0].tolist() == [3, 7]
