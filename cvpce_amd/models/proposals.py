@@ -31,6 +31,8 @@ ASPECT_RATIOS = (0.5, 1.0, 2.0)
 FPN_CHANNELS = 256
 USE_HEAD_ATLAS = True   # head towers on ONE atlas of the 5 pyramid levels (one launch per tower layer) instead of per level
 N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
+USE_DETECT_GRAPH = True   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
+MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image)
 
 
 # ---------------------------------------------------------------------------
@@ -276,12 +278,19 @@ class GLNEngine:
         self.tanh = subnet.tanh
 
     # -- stages ---------------------------------------------------------------
-    def transform(self, images):
+    @staticmethod
+    def batch_geometry(images):
+        """-> (original sizes, resized sizes, padded (Hp, Wp)) of GeneralizedRCNNTransform for this list of images."""
         sizes = [tuple(i.shape[-2:]) for i in images]
         rs = [resized_hw(h, w) for h, w in sizes]
         hp = int(math.ceil(max(r[0] for r in rs) / SIZE_DIVISIBLE) * SIZE_DIVISIBLE)
         wp = int(math.ceil(max(r[1] for r in rs) / SIZE_DIVISIBLE) * SIZE_DIVISIBLE)
-        batch = torch.empty((len(images), hp, wp, 8), dtype=torch.bfloat16, device=self.device)
+        return sizes, rs, (hp, wp)
+
+    def transform(self, images, out=None):
+        sizes, rs, (hp, wp) = self.batch_geometry(images)
+        batch = out if out is not None else torch.empty((len(images), hp, wp, 8), dtype=torch.bfloat16, device=self.device)
+        assert tuple(batch.shape) == (len(images), hp, wp, 8)
         for i, (img, (h, w)) in enumerate(zip(images, rs)):
             ops.gln_transform_into(img.contiguous(), batch, i, h, w, IMAGE_MEAN, IMAGE_STD)
         return batch, sizes, rs
@@ -340,13 +349,14 @@ class GLNEngine:
         n = feats[0].shape[0]
         shapes = [(f.shape[1], f.shape[2]) for f in feats]
         key = tuple(shapes)
-        if getattr(self, '_atlas_key', None) != key:
+        cache = self.__dict__.setdefault('_atlas_cache', {})
+        if key not in cache:                 # (never inside a graph capture: the first call of a shape always runs eagerly)
             hc, wc, offs = self.atlas_layout(shapes)
             mask = torch.zeros(hc, wc, dtype=torch.uint8)
             for (h, w), (oy, ox) in zip(shapes, offs):
                 mask[oy:oy + h, ox:ox + w] = 1
-            self._atlas_key, self._atlas = key, (hc, wc, offs, mask.to(self.device))
-        hc, wc, offs, mask = self._atlas
+            cache[key] = (hc, wc, offs, mask.to(self.device))
+        hc, wc, offs, mask = cache[key]
         atlas = torch.zeros(n, hc, wc, feats[0].shape[3], dtype=feats[0].dtype, device=self.device)
         for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
             atlas[:, oy:oy + h, ox:ox + w] = f
@@ -422,20 +432,57 @@ class GLNEngine:
         regs = [r.view(n, -1, 4) for r in reg]
         # per-batch-shape constants, cached: an H2D copy here would block the host behind the whole detector
         key = (tuple(resized), tuple(original))
-        if getattr(self, '_pp_key', None) != key:
+        cache = self.__dict__.setdefault('_pp_cache', {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
             image_hw = torch.tensor(resized, dtype=torch.int32).to(self.device)
             ratios = torch.stack([torch.tensor(o, dtype=torch.float32) / torch.tensor(r, dtype=torch.float32)
                                   for o, r in zip(original, resized)]).to(self.device)
             torch.cuda.current_stream().synchronize()
-            self._pp_key, self._pp_const = key, (image_hw, ratios)
-        image_hw, ratios = self._pp_const
+            cache[key] = (image_hw, ratios)
+        image_hw, ratios = cache[key]
         return ops.detect_postprocess(logits, regs, grids, strides, self.base_anchors, image_hw, ratios,
                                       self.num_anchors, num_classes, TOPK_CANDIDATES, SCORE_THRESH, NMS_THRESH,
                                       BBOX_XFORM_CLIP, detections_per_img, conf_thresh)
 
     def detect(self, images, num_classes, detections_per_img, conf_thresh=0.5, want_intermediates=False):
-        """-> (boxes (N,dpi,4), scores, labels, count, conf_count, gaussians (N,1,H/2,W/2)) all on device."""
+        """-> (boxes (N,dpi,4), scores, labels, count, conf_count, gaussians (N,1,H/2,W/2)) all on device.
+
+        The launch schedule after the transform depends only on the batch geometry, so from the second call of a geometry on
+        it is captured into a hipGraph and replayed: ~140 kernel launches become one graph launch (the host cost of the
+        Python -> dispatcher -> ctypes path per launch disappears; the kernels and their results are the same, bit for bit)."""
+        if USE_DETECT_GRAPH and not want_intermediates and ops.PROFILE is None:
+            return self._detect_graphed(images, num_classes, detections_per_img, conf_thresh)
         batch, original, resized = self.transform(images)
+        return self._detect_tail(batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates)
+
+    def _detect_graphed(self, images, num_classes, detections_per_img, conf_thresh):
+        original, resized, padded = self.batch_geometry(images)
+        key = (len(images), padded, tuple(resized), tuple(original), num_classes, detections_per_img, float(conf_thresh))
+        graphs = self.__dict__.setdefault('_graphs', {})
+        entry = graphs.get(key)
+        if entry is None:                                  # first sight of this geometry: eager (also fills the host-side caches)
+            while len(graphs) >= MAX_DETECT_GRAPHS:
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = {'graph': None}
+            batch, original, resized = self.transform(images)
+            return self._detect_tail(batch, original, resized, num_classes, detections_per_img, conf_thresh, False)
+        if entry['graph'] is None:                         # second call: capture
+            static_in = torch.empty((len(images), padded[0], padded[1], 8), dtype=torch.bfloat16, device=self.device)
+            self.transform(images, out=static_in)
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
+            entry.update(graph=g, static_in=static_in, static_out=static_out)
+        else:
+            self.transform(images, out=entry['static_in'])
+        entry['graph'].replay()
+        # results leave the graph's private memory: a later replay must not overwrite what the caller still holds
+        return tuple(t.clone() for t in entry['static_out'])
+
+    def _detect_tail(self, batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates):
         c2, c3, c4, c5 = self.body(batch)
         feats = self.fpn(c3, c4, c5)
         gauss = self.gaussian_branch(c2, feats[0])

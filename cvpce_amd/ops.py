@@ -1,8 +1,9 @@
-"""Tensor-level wrappers over the C ABI (include/cvpce_amd.h).
+"""Tensor-level wrappers of the hot-path kernels.
 
-torch is plumbing here: device memory (tensors), the current HIP stream and
-nothing else.  Every op runs a hand-written HIP kernel from libcvpce_hip.so;
-CPU tensors are rejected loudly.
+Layering: this module (shapes, output allocation, kernel choice) -> `torch.ops.cvpce_amd.*` (cvpce_amd/torch_ops.py: the
+PyTorch-ROCm custom ops, CUDA/HIP dispatch key only) -> ctypes -> the C ABI of include/cvpce_amd.h -> hand-written HIP
+kernels in libcvpce_hip.so.  torch is plumbing: device memory (tensors), the current HIP stream, the dispatcher.  There is
+no CPU kernel anywhere: CPU tensors are rejected loudly.
 """
 import ctypes
 import math
@@ -13,6 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check
+from .torch_ops import T
 
 BF16 = torch.bfloat16
 
@@ -142,9 +144,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         e0.record()
     if halo:
         # (Cout <= 128 is forwarded to the wide-tile kernel, conv3x3_halo3.hip, inside the library)
-        rc = lib.cvpce_conv3x3_halo(_p(x), _p(pc.weight), _p(pc.bias), _p(out), n, h, w, cin, pc.cout, pc.k_pad,
-                                    pc.cout_pad, int(act), int(pool), _stream())
-        check(rc, 'cvpce_conv3x3_halo')
+        T.conv3x3_halo(x, pc.weight, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool))
         if prof is not None:
             e1.record()
             prof.records.append(('conv3x3_halo3_kernel' if pc.cout <= 128 else 'conv3x3_halo2_kernel',
@@ -153,19 +153,13 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
     if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
             and (CONV1X1_ANY_SHAPE or (cin <= 256 and pc.cout >= 4 * cin)) and pc.cout % 64 == 0 and not out_f32 and not in_up_shift and not pool and act in (0, 1) and n * h * w * cin * 2 < 2 ** 32):
-        rc = lib.cvpce_conv1x1_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout, pc.stride,
-                                         ho, wo, pc.k_pad, pc.cout_pad, int(act), int(res_mode if residual is not None else 0),
-                                         hr, wr, _stream())
-        check(rc, 'cvpce_conv1x1_nhwc_bf16')
+        T.conv1x1_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.stride, ho, wo, pc.k_pad, pc.cout_pad, int(act), int(res_mode))
         if prof is not None:
             e1.record()
             prof.records.append(('conv1x1_kernel', 2.0 * n * ho * wo * pc.cout * pc.cin, e0, e1))
         return out
-    rc = lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(pc.weight), _p(pc.bias), _p(residual), _p(out), n, h, w, cin, pc.cout,
-                                    pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad, int(act),
-                                    int(out_f32), int(in_up_shift), int(res_mode if residual is not None else 0),
-                                    hr, wr, int(pool), int(FORCE_GENERIC_CONV), _stream())   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
-    check(rc, 'cvpce_conv2d_nhwc_bf16')
+    T.conv2d_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
+                  int(act), int(out_f32), int(in_up_shift), int(res_mode), int(pool), int(FORCE_GENERIC_CONV))   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
     if prof is not None:
         e1.record()
         # algorithmic FLOPs: real (unpadded) channels, 2 FLOP per MAC
@@ -202,8 +196,7 @@ def conv3x3_atlas(x, pc, mask, act=1):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.cvpce_conv3x3_halo_masked(_p(x), _p(pc.weight), _p(pc.bias), _p(mask), _p(out), n, h, w, cin, pc.cout,
-                                        pc.k_pad, pc.cout_pad, int(act), _stream()), 'cvpce_conv3x3_halo_masked')
+    T.conv3x3_halo_masked(x, pc.weight, pc.bias, mask, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
     if prof is not None:
         e1.record()
         prof.records.append(('conv3x3_halo2_kernel' ,
@@ -221,8 +214,7 @@ def vgg_stem(x, ps):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(ps.w1), _p(ps.b1), _p(ps.w2), _p(ps.b2), _p(out), n, h, w, _stream()),
-          'cvpce_vgg_stem_fused')
+    T.vgg_stem_fused(x, ps.w1, ps.b1, ps.w2, ps.b2, out)
     if prof is not None:
         e1.record()
         prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
@@ -234,14 +226,14 @@ def maxpool2d(x, k, stride, pad=0):
     n, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     out = torch.empty((n, ho, wo, c), dtype=BF16, device=x.device)
-    check(lib.cvpce_maxpool2d_nhwc_bf16(_p(x), _p(out), n, h, w, c, k, stride, pad, ho, wo, _stream()), 'maxpool')
+    T.maxpool2d_nhwc(x, out, k, stride, pad)
     return out
 
 
 def relu(x):
     _need_cuda(x)
     out = torch.empty_like(x)
-    check(lib.cvpce_relu_bf16(_p(x), _p(out), x.numel(), _stream()), 'relu')
+    T.relu(x, out)
     return out
 
 
@@ -249,14 +241,14 @@ def global_max_into(x, out, out_off):
     """x NHWC bf16 -> out[:, out_off:out_off+C] (f32) = amax over H,W."""
     _need_cuda(x, out)
     n, h, w, c = x.shape
-    check(lib.cvpce_global_max_nhwc_bf16(_p(x), _p(out), n, h * w, c, out.shape[1], out_off, _stream()), 'global_max')
+    T.global_max_nhwc(x, out, out_off)
 
 
 def l2_normalize(desc, eps=1e-8, want_bf16=False):
     _need_cuda(desc)
     out = torch.empty_like(desc)
     out_bf = torch.empty(desc.shape, dtype=BF16, device=desc.device) if want_bf16 else None
-    check(lib.cvpce_l2_normalize_f32(_p(desc), _p(out), _p(out_bf), desc.shape[0], desc.shape[1], eps, _stream()), 'l2norm')
+    T.l2_normalize(desc, out, out_bf, float(eps))
     return (out, out_bf) if want_bf16 else out
 
 
@@ -269,8 +261,7 @@ def gln_transform_into(img, batch, index, h, w, mean, std):
     assert img.dtype == torch.float32 and img.is_contiguous()
     _, hp, wp, c8 = batch.shape
     assert c8 == 8
-    check(lib.cvpce_gln_transform(_p(img), ctypes.c_void_p(batch[index].data_ptr()), img.shape[1], img.shape[2], h, w,
-                                  hp, wp, _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform')
+    T.gln_transform(img, batch, index, h, w, [float(v) for v in mean], [float(v) for v in std])
 
 
 MAX_CROPS_PER_LAUNCH = 65535
@@ -285,17 +276,15 @@ def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, o
     if out is None:
         out = (torch.empty((p, 3, size, size), dtype=torch.float32, device=img.device) if mode == 0
                else torch.empty((p, size, size, 8), dtype=BF16, device=img.device))
-    m = _lib.float3(mean) if mean is not None else None
-    s = _lib.float3(std) if std is not None else None
+    m = [float(v) for v in mean] if mean is not None else None
+    s = [float(v) for v in std] if std is not None else None
     for start in range(0, p, MAX_CROPS_PER_LAUNCH):
         nb = min(MAX_CROPS_PER_LAUNCH, p - start)
         cnt = None
         if count is not None:
             assert start == 0 and p <= MAX_CROPS_PER_LAUNCH
             cnt = count
-        check(lib.cvpce_crop_resize(_p(img), ctypes.c_void_p(boxes[start:].data_ptr()), _p(cnt), nb,
-                                    ctypes.c_void_p(out[start:].data_ptr()), img.shape[1], img.shape[2], size, mode,
-                                    m, s, _stream()), 'crop_resize')
+        T.crop_resize(img, boxes[start:start + nb], cnt, out[start:start + nb], size, mode, m, s)
     return out
 
 
@@ -306,8 +295,7 @@ def pack_embed_input(images, to_tanh, mean, std):
     b, _, s, s2 = images.shape
     assert s == s2
     out = torch.empty((b, s, s, 8), dtype=BF16, device=images.device)
-    check(lib.cvpce_pack_embed_input(_p(images), _p(out), b, s, int(to_tanh), _lib.float3(mean), _lib.float3(std),
-                                     _stream()), 'pack_embed_input')
+    T.pack_embed_input(images, out, int(to_tanh), [float(v) for v in mean], [float(v) for v in std])
     return out
 
 
@@ -332,16 +320,9 @@ def detect_postprocess(logits, regs, grids, strides, base_anchors, image_hw, rat
     conf = torch.zeros((n,), dtype=torch.int32, device=dev)
     for t in list(logits) + list(regs):
         assert t.dtype == torch.float32 and t.is_contiguous()
-    lp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in logits])
-    rp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in regs])
-    ci = lambda v: (ctypes.c_int * L)(*[int(x) for x in v])
-    rc = lib.cvpce_detect_postprocess(lp, rp, ci([g[0] for g in grids]), ci([g[1] for g in grids]),
-                                      ci([s[0] for s in strides]), ci([s[1] for s in strides]),
-                                      _p(base_anchors), _p(image_hw), _p(ratios), L, n, num_anchors, num_classes,
-                                      topk, score_thresh, nms_thresh, xform_clip, detections_per_img, conf_thresh,
-                                      _p(ws), ws_bytes, _p(boxes), _p(scores), _p(labels), _p(count), _p(conf),
-                                      _stream())
-    check(rc, 'cvpce_detect_postprocess')
+    T.detect_postprocess(list(logits), list(regs), [int(g[0]) for g in grids], [int(g[1]) for g in grids], [int(s[0]) for s in strides],
+                         [int(s[1]) for s in strides], base_anchors, image_hw, ratios, num_anchors, num_classes, topk, float(score_thresh),
+                         float(nms_thresh), float(xform_clip), detections_per_img, float(conf_thresh), ws, boxes, scores, labels, count, conf)
     return boxes, scores, labels, count, conf
 
 
@@ -352,8 +333,7 @@ def row_norms(x, eps=1e-8):
     _need_cuda(x)
     assert x.is_contiguous() and x.dtype in (BF16, torch.float32)
     out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
-    check(lib.cvpce_row_norms(_p(x), _p(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32), eps, _stream()),
-          'row_norms')
+    T.row_norms(x, out, float(eps))
     return out
 
 
@@ -376,9 +356,7 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
     idx = torch.empty((qn, k), dtype=torch.int64, device=queries.device)
     dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
-    rc = lib.cvpce_match_topk(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), qn, gn, d, k,
-                              int(queries.dtype == torch.float32), _p(ws), ws_bytes, _p(idx), _p(dist), _stream())
-    check(rc, 'cvpce_match_topk')
+    T.match_topk(queries, gallery, q_norms, g_norms, k, ws, idx, dist)
     return (idx, dist) if return_distance else idx
 
 
@@ -403,7 +381,7 @@ def probe_mfma_bf16(shape, seconds=2.0, iters=20000, workgroups=256):
     operands = torch.randn(1 << 16, device=dev).to(BF16)
     sink = torch.empty(workgroups * 256, dtype=torch.float32, device=dev)
     flop = workgroups * 4 * iters * 16 * (32768 if shape == 0 else 16384)
-    launch = lambda: check(lib.cvpce_probe_mfma_bf16(int(shape), int(iters), _p(operands), _p(sink), int(workgroups), _stream()), 'probe')
+    launch = lambda: T.probe_mfma_bf16(int(shape), int(iters), operands, sink, int(workgroups))
     launch()
     torch.cuda.synchronize()
     t0, n = time.perf_counter(), 0

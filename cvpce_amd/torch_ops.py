@@ -1,0 +1,157 @@
+"""PyTorch-ROCm custom ops over the C ABI: `torch.ops.cvpce_amd.*` (north_star: "hand-written CDNA4 HIP kernels exposed
+to Python through PyTorch-ROCm custom ops").
+
+One dispatcher entry per C-ABI entry point of include/cvpce_amd.h, registered with `torch.library` for the CUDA (= HIP on
+ROCm) dispatch key ONLY: there is no CPU kernel, so a CPU tensor fails in the dispatcher ("no CPU fallback" holds at the
+op level too).  All ops are out-variants -- the caller (cvpce_amd/ops.py) allocates, the op launches one hand-written
+kernel schedule on the current HIP stream through ctypes -> libcvpce_hip.so, no allocation, no synchronisation -- so they
+are safe under HIP stream capture (cvpce_amd.models.proposals captures the detector schedule in a hipGraph).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_L = torch.library.Library('cvpce_amd', 'DEF')
+NAMES = []
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _op(schema):
+    def deco(fn):
+        name = schema.split('(')[0]
+        _L.define(schema)
+        _L.impl(name, fn, 'CUDA')
+        NAMES.append(name)
+        return fn
+    return deco
+
+
+@_op('conv2d_nhwc(Tensor x, Tensor weight, Tensor? bias, Tensor? residual, Tensor(a!) out, int cout, int kh, int kw, int stride, '
+     'int pad, int ho, int wo, int k_pad, int cout_pad, int act, int out_f32, int in_up_shift, int res_mode, int pool, '
+     'int force_generic) -> ()')
+def _conv2d_nhwc(x, weight, bias, residual, out, cout, kh, kw, stride, pad, ho, wo, k_pad, cout_pad, act, out_f32, in_up_shift,
+                 res_mode, pool, force_generic):
+    n, h, w, cin = x.shape
+    hr, wr = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    check(lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, kh, kw, stride, pad, ho, wo,
+                                     k_pad, cout_pad, act, out_f32, in_up_shift, res_mode if residual is not None else 0, hr, wr, pool,
+                                     force_generic, _stream()), 'cvpce_conv2d_nhwc_bf16')
+
+
+@_op('conv1x1_nhwc(Tensor x, Tensor weight, Tensor? bias, Tensor? residual, Tensor(a!) out, int cout, int stride, int ho, int wo, '
+     'int k_pad, int cout_pad, int relu, int res_mode) -> ()')
+def _conv1x1_nhwc(x, weight, bias, residual, out, cout, stride, ho, wo, k_pad, cout_pad, relu, res_mode):
+    n, h, w, cin = x.shape
+    hr, wr = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    check(lib.cvpce_conv1x1_nhwc_bf16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, stride, ho, wo, k_pad,
+                                      cout_pad, relu, res_mode if residual is not None else 0, hr, wr, _stream()), 'cvpce_conv1x1_nhwc_bf16')
+
+
+@_op('conv3x3_halo(Tensor x, Tensor weight, Tensor? bias, Tensor(a!) out, int cout, int k_pad, int cout_pad, int relu, int pool) -> ()')
+def _conv3x3_halo(x, weight, bias, out, cout, k_pad, cout_pad, relu, pool):
+    n, h, w, cin = x.shape
+    check(lib.cvpce_conv3x3_halo(_p(x), _p(weight), _p(bias), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, pool, _stream()),
+          'cvpce_conv3x3_halo')
+
+
+@_op('conv3x3_halo_masked(Tensor x, Tensor weight, Tensor? bias, Tensor mask, Tensor(a!) out, int cout, int k_pad, int cout_pad, '
+     'int relu) -> ()')
+def _conv3x3_halo_masked(x, weight, bias, mask, out, cout, k_pad, cout_pad, relu):
+    n, h, w, cin = x.shape
+    check(lib.cvpce_conv3x3_halo_masked(_p(x), _p(weight), _p(bias), _p(mask), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu,
+                                        _stream()), 'cvpce_conv3x3_halo_masked')
+
+
+@_op('vgg_stem_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out) -> ()')
+def _vgg_stem_fused(x, w1, b1, w2, b2, out):
+    n, h, w, c = x.shape
+    check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(w1), _p(b1), _p(w2), _p(b2), _p(out), n, h, w, _stream()), 'cvpce_vgg_stem_fused')
+
+
+@_op('maxpool2d_nhwc(Tensor x, Tensor(a!) out, int k, int stride, int pad) -> ()')
+def _maxpool2d_nhwc(x, out, k, stride, pad):
+    n, h, w, c = x.shape
+    check(lib.cvpce_maxpool2d_nhwc_bf16(_p(x), _p(out), n, h, w, c, k, stride, pad, out.shape[1], out.shape[2], _stream()), 'maxpool')
+
+
+@_op('relu(Tensor x, Tensor(a!) out) -> ()')
+def _relu(x, out):
+    check(lib.cvpce_relu_bf16(_p(x), _p(out), x.numel(), _stream()), 'relu')
+
+
+@_op('global_max_nhwc(Tensor x, Tensor(a!) out, int out_off) -> ()')
+def _global_max_nhwc(x, out, out_off):
+    n, h, w, c = x.shape
+    check(lib.cvpce_global_max_nhwc_bf16(_p(x), _p(out), n, h * w, c, out.shape[1], out_off, _stream()), 'global_max')
+
+
+@_op('l2_normalize(Tensor x, Tensor(a!) out, Tensor(b!)? out_bf16, float eps) -> ()')
+def _l2_normalize(x, out, out_bf16, eps):
+    check(lib.cvpce_l2_normalize_f32(_p(x), _p(out), _p(out_bf16), x.shape[0], x.shape[1], eps, _stream()), 'l2norm')
+
+
+@_op('gln_transform(Tensor img, Tensor(a!) batch, int index, int h, int w, float[] mean, float[] std) -> ()')
+def _gln_transform(img, batch, index, h, w, mean, std):
+    _, hp, wp, _ = batch.shape
+    check(lib.cvpce_gln_transform(_p(img), ctypes.c_void_p(batch[index].data_ptr()), img.shape[1], img.shape[2], h, w, hp, wp,
+                                  _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform')
+
+
+@_op('crop_resize(Tensor img, Tensor boxes, Tensor? count, Tensor(a!) out, int size, int mode, float[]? mean, float[]? std) -> ()')
+def _crop_resize(img, boxes, count, out, size, mode, mean, std):
+    check(lib.cvpce_crop_resize(_p(img), _p(boxes), _p(count), boxes.shape[0], _p(out), img.shape[1], img.shape[2], size, mode,
+                                _lib.float3(mean) if mean is not None else None, _lib.float3(std) if std is not None else None,
+                                _stream()), 'crop_resize')
+
+
+@_op('pack_embed_input(Tensor images, Tensor(a!) out, int to_tanh, float[] mean, float[] std) -> ()')
+def _pack_embed_input(images, out, to_tanh, mean, std):
+    check(lib.cvpce_pack_embed_input(_p(images), _p(out), images.shape[0], images.shape[2], to_tanh, _lib.float3(mean), _lib.float3(std),
+                                     _stream()), 'pack_embed_input')
+
+
+@_op('detect_postprocess(Tensor[] logits, Tensor[] regs, int[] gh, int[] gw, int[] sh, int[] sw, Tensor base_anchors, Tensor image_hw, '
+     'Tensor ratios, int num_anchors, int num_classes, int topk, float score_thresh, float nms_thresh, float xform_clip, '
+     'int detections_per_img, float conf_thresh, Tensor(a!) workspace, Tensor(b!) boxes, Tensor(c!) scores, Tensor(d!) labels, '
+     'Tensor(e!) count, Tensor(f!) conf) -> ()')
+def _detect_postprocess(logits, regs, gh, gw, sh, sw, base_anchors, image_hw, ratios, num_anchors, num_classes, topk, score_thresh,
+                        nms_thresh, xform_clip, detections_per_img, conf_thresh, workspace, boxes, scores, labels, count, conf):
+    L, n = len(logits), logits[0].shape[0]
+    lp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in logits])
+    rp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in regs])
+    ci = lambda v: (ctypes.c_int * L)(*[int(x) for x in v])
+    check(lib.cvpce_detect_postprocess(lp, rp, ci(gh), ci(gw), ci(sh), ci(sw), _p(base_anchors), _p(image_hw), _p(ratios), L, n,
+                                       num_anchors, num_classes, topk, score_thresh, nms_thresh, xform_clip, detections_per_img,
+                                       conf_thresh, _p(workspace), workspace.numel(), _p(boxes), _p(scores), _p(labels), _p(count),
+                                       _p(conf), _stream()), 'cvpce_detect_postprocess')
+
+
+@_op('row_norms(Tensor x, Tensor(a!) out, float eps) -> ()')
+def _row_norms(x, out, eps):
+    check(lib.cvpce_row_norms(_p(x), _p(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32), eps, _stream()), 'row_norms')
+
+
+@_op('match_topk(Tensor queries, Tensor gallery, Tensor q_norms, Tensor g_norms, int k, Tensor(a!) workspace, Tensor(b!) idx, '
+     'Tensor(c!)? dist) -> ()')
+def _match_topk(queries, gallery, q_norms, g_norms, k, workspace, idx, dist):
+    check(lib.cvpce_match_topk(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), queries.shape[0], gallery.shape[0], queries.shape[1], k,
+                               int(queries.dtype == torch.float32), _p(workspace), workspace.numel(), _p(idx), _p(dist), _stream()),
+          'cvpce_match_topk')
+
+
+@_op('probe_mfma_bf16(int shape, int iters, Tensor operands, Tensor(a!) sink, int workgroups) -> ()')
+def _probe_mfma_bf16(shape, iters, operands, sink, workgroups):
+    check(lib.cvpce_probe_mfma_bf16(shape, iters, _p(operands), _p(sink), workgroups, _stream()), 'probe')
+
+
+T = torch.ops.cvpce_amd

@@ -82,8 +82,26 @@ def oracle_embed(x_tanh, sd, device, batch=32):
 
 
 @torch.no_grad()
+def emulated_detect(img, sd, dpi):
+    """The detector evaluated by oracle/bf16_model.py: the SAME graph as the fp32 oracle with the rounding points of the HIP
+    schedule (BN folded, weights and inter-layer activations rounded to bf16, fp32 accumulation, fp32 head outputs), then the
+    oracle's own post-processing.  Not an oracle: a CONTROL that separates "bf16 storage moves near-tie decisions" (this
+    model deviates from the fp32 oracle as much as the HIP path does) from "the kernels are wrong" (the HIP path would
+    deviate from this model too)."""
+    from oracle import gln as og, bf16_model as bm
+    x = og.transform_one(img)
+    batch = og.batch_images([x])
+    c2, c3, c4, c5 = bm.body(batch, sd)
+    feats = bm.fpn(c3, c4, c5, sd)
+    cls, reg = bm.heads(feats, sd)
+    anchors = og.grid_anchors(tuple(batch.shape[-2:]), [tuple(f.shape[-2:]) for f in feats])
+    b, s_, l = og.postprocess_image([c[0] for c in cls], [r[0] for r in reg], anchors, tuple(x.shape[-2:]), dpi)
+    return {'boxes': og.resize_boxes(b, tuple(x.shape[-2:]), tuple(img.shape[-2:])), 'scores': s_}
+
+
+@torch.no_grad()
 def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
-        k=5, images_per_batch=8, seed=0, log=None):
+        k=5, images_per_batch=8, seed=0, control_images=0, log=None):
     from cvpce_amd import ops, production, synthetic, datautils
     from oracle import gln as og, crop as ocrop, match as omatch
     log = log or (lambda *a: None)
@@ -163,6 +181,21 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
                       'ar300_hip': a_h[0.5]['ar_300'], 'ar300_oracle': a_o[0.5]['ar_300'],
                       'delta_ar300_pt': 100 * (a_h[0.5]['ar_300'] - a_o[0.5]['ar_300'])},
         'gt': {'ap50_hip': g_h[0.5]['ap'], 'ap50_oracle': g_o[0.5]['ap'], 'delta_pt': 100 * (g_h[0.5]['ap'] - g_o[0.5]['ap'])}}
+
+    if control_images:
+        t = time.perf_counter()
+        m = min(control_images, n_images)
+        emu = [emulated_detect(sh[0], det_sd, dpi) for sh in shelves[:m]]
+        eb, es = [e['boxes'] for e in emu], [e['scores'] for e in emu]
+        e_vs_o, h_vs_e, h_vs_o = _ap(ob[:m], eb, es), _ap(eb, hb[:m], hs[:m]), _ap(ob[:m], hb[:m], hs[:m])
+        frac = lambda a, b: sum(len(pair_boxes(x, y)) for x, y in zip(a, b)) / max(1, sum(len(y) for y in b))
+        report['detection']['control_bf16_emulation'] = {
+            'images': m,
+            'what': 'oracle/bf16_model.py = the fp32 oracle graph with the HIP schedule\'s bf16 rounding points, on the CPU',
+            'emulation_vs_oracle': {'ap50': e_vs_o[0.5]['ap'], 'ar300': e_vs_o[0.5]['ar_300'], 'frac_boxes_iou90': frac(eb, ob[:m])},
+            'hip_vs_oracle_same_images': {'ap50': h_vs_o[0.5]['ap'], 'ar300': h_vs_o[0.5]['ar_300'], 'frac_boxes_iou90': frac(hb[:m], ob[:m])},
+            'hip_vs_emulation': {'ap50': h_vs_e[0.5]['ap'], 'ar300': h_vs_e[0.5]['ar_300'], 'frac_boxes_iou90': frac(hb[:m], eb)}}
+        log(f'[accuracy] bf16-emulation control on {m} images ({time.perf_counter() - t:.1f} s)')
 
     # ---- matching: paired detections ------------------------------------------------------------------------------------
     gen = torch.Generator().manual_seed(77 + seed)
@@ -250,11 +283,12 @@ def main():
     ap.add_argument('--queries', type=int, default=1024)
     ap.add_argument('--detections-per-img', type=int, default=200)
     ap.add_argument('--oracle-device', default='cpu', choices=['cpu', 'cuda'])
+    ap.add_argument('--control-images', type=int, default=8, help='images of the bf16-emulation control (oracle/bf16_model.py)')
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     rep = run(a.images, a.image_size, tuple(int(g) for g in a.galleries.split(',')), a.detections_per_img, a.queries, a.oracle_device,
-              log=lambda *x: print(*x, flush=True))
+              control_images=a.control_images, log=lambda *x: print(*x, flush=True))
     text = json.dumps(rep, indent=1)
     print(text)
     if a.out:

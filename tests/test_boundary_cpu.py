@@ -36,6 +36,25 @@ def test_workspace_queries_are_host_only():
     assert lib.cvpce_match_workspace_bytes(1600, 3200, 1) >= 1600 * 25 * 8
 
 
+def test_torch_ops_registered_for_the_gpu_only():
+    """north_star: "exposed to Python through PyTorch-ROCm custom ops".  One dispatcher entry per C-ABI compute entry point,
+    CUDA (= HIP) key only: a CPU tensor is refused by the dispatcher itself -- no CPU kernel exists to fall back to."""
+    from cvpce_amd import torch_ops
+    declared = {s for s in header_symbols() if not s.endswith('_bytes') and s != 'cvpce_set_persistent_workgroups'}
+    # (the two 3x3 halo entry points share one op: Cout <= 128 is forwarded to the wide-tile kernel inside the library)
+    assert len(torch_ops.NAMES) == len(declared) - 1 == 16
+    for name in torch_ops.NAMES:
+        op = getattr(torch.ops.cvpce_amd, name)
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'cvpce_amd::{name}', 'CPU')
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'cvpce_amd::{name}', 'CUDA')
+    x = torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError, match='CPU'):
+        torch.ops.cvpce_amd.relu(x, x.clone())
+    with pytest.raises(NotImplementedError, match='CPU'):
+        torch.ops.cvpce_amd.match_topk(torch.zeros(2, 64), torch.zeros(3, 64), torch.ones(2), torch.ones(3), 1,
+                                       torch.zeros(64, dtype=torch.uint8), torch.zeros(2, 1, dtype=torch.int64), None)
+
+
 def test_product_never_imports_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'cvpce_amd')):
