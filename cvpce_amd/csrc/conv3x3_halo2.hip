@@ -14,6 +14,14 @@
 //     the 18 patch rows ONCE (ds_read_b128, immediate offsets, 4-deep register ring) and issues up to 6 MFMAs on it:
 //     108 fragment reads per chunk instead of 288 -- the reads were 21 % of conv4_2 (profiles/r01d_ablation_halo2.md).
 // Per chunk and wave: 6 steps x (18 ds_read_b128 + 96 MFMA 16x16x32 + 6 weight loads).
+//   * STAGGER: the two waves of a SIMD (w and w + 4) run the same program; in lock step they would reach their tile
+//     epilogues (VALU + stores, no MFMA) together and leave the matrix pipe idle -- the shallow-K layers lost 10-25 % to
+//     that (conv3_1 1340 vs conv4_2 1540 TFLOP/s).  Waves 4-7 therefore take the per-chunk hand-off (vmcnt wait, barrier,
+//     next patch DMA) after step 2 instead of step 5: the SAME barrier instance pairs "waves 0-3 at the end of chunk c"
+//     with "waves 4-7 in the middle of chunk c", which pins them half a chunk behind, so one half's epilogue always runs
+//     beside the other half's MFMA stream.  The hazards are unchanged: the DMA into the buffer of chunk c-1 is issued
+//     after a barrier every wave reaches with chunk c-1 behind it, and a chunk's patch is read only after a barrier
+//     every wave passed with its pieces landed (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
 // K order / weight layout: chunk-major [Cout_pad][K_pad] of include/cvpce_amd.h.  Fused bias / ReLU / MaxPool2d(2,2).
 #include "common.h"
 #include "../../include/cvpce_amd.h"
@@ -23,7 +31,8 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 // compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 no s_setprio around the MFMA
 // groups, 2 XCD-aware tile order, 4 no patch DMA in the loop, 8 no weight loads in the loop, 16 no output stores,
-// 32 no fragment reads in the loop, 64 no hand-off barrier (races: timing only)
+// 32 no fragment reads in the loop, 64 no hand-off barrier (races: timing only), 128 no stagger (all waves hand off after
+// step 5: the pre-stagger schedule, results identical)
 #ifndef CVPCE_DBG
 #define CVPCE_DBG 0
 #endif
@@ -47,13 +56,15 @@ struct Halo2Args {
     const bf16_t* wgt;   // [Cout_pad][K_pad], chunk-major K
     const float* bias;
     const unsigned char* mask;   // optional [H][W]: output pixels with mask 0 are stored as zeros (atlas gaps); not with POOL
-    bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]
+    bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]; null with gmax: nothing is stored (conv5_3)
+    float* gmax;         // optional MAC descriptor [N][gmax_stride]: gmax[n][gmax_off + co] = max over the map (relu = 1)
+    int gmax_stride, gmax_off;
     int N, H, W, Cin, Cout, K_pad, relu;
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
 };
 
-template <bool POOL>
+template <bool POOL, bool GMAX>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     constexpr int TC = 256, NB = 16;
 
@@ -206,16 +217,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #define G2_ROWS_0_15(T)                                                                                        \
     G2_RP(T, 0) G2_RP(T, 1) G2_RP(T, 2) G2_RP(T, 3) G2_RP(T, 4) G2_RP(T, 5) G2_RP(T, 6) G2_RP(T, 7)            \
     G2_RP(T, 8) G2_RP(T, 9) G2_RP(T, 10) G2_RP(T, 11) G2_RP(T, 12) G2_RP(T, 13) G2_RP(T, 14) G2_RP(T, 15)
-    // step T < 5: fetch the next step's weights, stream the rows; rows 16, 17 prefetch rows 0, 1 of step T + 1
-#define G2_STEP(T)                                                                                             \
+    // the chunk hand-off: this wave is done with the PREVIOUS chunk's buffer and (vmcnt) its own pieces of the NEXT chunk's
+    // patch have landed -- at most the 6 weight loads just issued are younger than those pieces; then the DMA of the chunk
+    // after the next one goes into the buffer the previous chunk used
+#define G2_HANDOFF()                                                                                           \
+    {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
+        if (!(CVPCE_DBG & 64)) __builtin_amdgcn_s_barrier();                                                   \
+        issue_next_patch();                                                                                    \
+    }
+    // step T < 5: fetch the next step's weights, stream the rows; rows 16, 17 prefetch rows 0, 1 of step T + 1.
+    // HANDOFF: a wave-uniform condition -- the late half (waves 4-7) takes the chunk hand-off here, after step 2
+#define G2_STEP_H(T, HANDOFF)                                                                                  \
     {                                                                                                          \
         G2_LOAD_A((T) + 1, sb_cur)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         G2_ROWS_0_15(T)                                                                                        \
+        if (HANDOFF) G2_HANDOFF()                                                                              \
         G2_SET_E((T) + 1, bufb)                                                                                \
         G2_READ((T) + 1, 0) G2_ROW(T, 16)                                                                      \
         G2_READ((T) + 1, 1) G2_ROW(T, 17)                                                                      \
     }
+#define G2_STEP(T) G2_STEP_H(T, false)
 
     // ---- prologue ----
     int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct;
@@ -249,24 +272,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     G2_READ(0, 1)
 
     const int lp = lane & 15;
+    const bool late = (wc >= 4) && !(CVPCE_DBG & 128);   // the second-dispatched half: SIMD partners of waves 0-3 (128: no stagger)
     for (int cc = 0; cc < total_chunks; ++cc) {
         // keep the per-step address variants inside the loop: hoisted they cost VGPRs the accumulators need
         asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
-        G2_STEP(0) G2_STEP(1) G2_STEP(2) G2_STEP(3) G2_STEP(4)
-        // ---- last step of the chunk, with the chunk hand-off before its rows 16, 17 prefetch from the NEXT buffer ----
+        G2_STEP(0) G2_STEP(1) G2_STEP_H(2, late) G2_STEP(3) G2_STEP(4)
+        // ---- last step of the chunk; the early half takes the chunk hand-off here, before rows 16, 17 prefetch from the
+        //      NEXT buffer (whose pieces the late half saw landed at its own hand-off, half a chunk ago) ----
         {
             G2_LOAD_A(0, sb_next)        // step 0 of the next chunk (slot 0); past the last chunk a harmless reload
             __builtin_amdgcn_sched_barrier(0);
             G2_ROWS_0_15(5)
-            // every wave is done with the PREVIOUS chunk's buffer and (vmcnt) its own pieces of the NEXT chunk's patch
-            // have landed: at most the 6 weight loads just issued are younger than those pieces.  After the last chunk
-            // the barrier, the reads and the weight loads still run -- on valid, unused data -- so that the loop body
-            // has one shape and the accumulators stay in place.
+            // After the last chunk the barrier, the reads and the weight loads still run -- on valid, unused data -- so
+            // that the loop body has one shape and the accumulators stay in place.
             const int nbufi = (bufi == 2) ? 0 : bufi + 1;
             const unsigned nbufb = lds_a + (unsigned)nbufi * G2_A_BYTES;
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            if (!(CVPCE_DBG & 64)) __builtin_amdgcn_s_barrier();
-            issue_next_patch();                          // chunk cc + 2 -> the buffer chunk cc - 1 used
+            if (!late) G2_HANDOFF()                      // chunk cc + 2 -> the buffer chunk cc - 1 used
             G2_SET_E(0, nbufb)
             G2_READ(0, 0) G2_ROW(5, 16)
             G2_READ(0, 1) G2_ROW(5, 17)
@@ -282,7 +303,45 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
             load_bias(n_ct, nbias);
             const int col = g2_col(lp);
             const int co = ct * TC + wc * 32 + 8 * lq;            // this lane's 8 consecutive couts
-            if (POOL) {
+            if constexpr (GMAX) {
+                // MAC descriptor fused (classification.py:46-49 `x.amax(dim=(-2, -1))` of the post-ReLU map): maximum over
+                // the tile's 256 pixels per cout -- over the lane's 16 rows in registers, over the 16 pixel lanes of a DPP
+                // row by rotates -- then one atomic max per (tile, cout) into the zero-initialised descriptor.  Values are
+                // >= 0 after ReLU, so they order like their bit patterns; rounding to bf16 is monotonic, so the maximum
+                // of the fp32 values rounded once equals the maximum of the stored bf16 map, bit for bit.
+                unsigned m[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = 0u;
+                if (tx * G2_T + col < a.W) {
+#pragma unroll
+                    for (int nt = 0; nt < NB; ++nt)
+                        if (ty * G2_T + nt < a.H) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                m[j] = max(m[j], __float_as_uint(relu_bits(acc[0][nt][j])));
+                                m[4 + j] = max(m[4 + j], __float_as_uint(relu_bits(acc[1][nt][j])));
+                            }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned v = m[j];
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));   // row_ror:8
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));   // row_ror:4
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false));   // row_ror:2
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false));   // row_ror:1
+                    m[j] = v;
+                }
+                if (lp == 0) {
+                    unsigned* g = reinterpret_cast<unsigned*>(a.gmax) + (size_t)n * a.gmax_stride + a.gmax_off + co;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (co + j < a.Cout) atomicMax(g + j, __float_as_uint((float)f32_to_bf16(__uint_as_float(m[j]))));
+                }
+            }
+            if (GMAX && a.out == nullptr) {
+                // the map itself has no consumer (conv5_3: only its MAC descriptor is used): nothing to store
+            } else if (POOL) {
                 // rows 2i, 2i+1 are accumulator rows of the same lane; columns 2k, 2k+1 are lanes A[k], B[k] with
                 // A = {0-3,12-15}, B = {4-11}: lane A[k] takes its right neighbour by a row rotate (+4 for lanes 0-3,
                 // -4 for lanes 12-15; bank masks 1 and 8)
@@ -351,6 +410,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
 #undef G2_STEP
+#undef G2_STEP_H
+#undef G2_HANDOFF
 #undef G2_ROWS_0_15
 #undef G2_RP
 #undef G2_ROW
@@ -359,26 +420,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #undef G2_LOAD_A
 }
 
-template <bool POOL>
+template <bool POOL, bool GMAX>
 static int launch_halo2(Halo2Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 255) / 256;
     a.ntiles = a.ptiles * a.ctiles;
     const int smem = 3 * G2_A_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<POOL, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
-    hipLaunchKernelGGL((conv3x3_halo2_kernel<POOL>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo2_kernel<POOL, GMAX>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
-static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out, int N,
-                          int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out, float* gmax,
+                          int gmax_stride, int gmax_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                          int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
-    if (!in || !wgt || !out) return CVPCE_ERR_ARG;
+    if (!in || !wgt || (!out && !gmax)) return CVPCE_ERR_ARG;
+    if (gmax && (!relu || mask || Cout <= 128 || gmax_off < 0 || gmax_off + Cout > gmax_stride)) return CVPCE_ERR_ARG;
     if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
     if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
     if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
@@ -390,6 +453,7 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
         return cvpce_conv3x3_halo_wide(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
     Halo2Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = mask; a.out = (bf16_t*)out;
+    a.gmax = gmax; a.gmax_stride = gmax_stride; a.gmax_off = gmax_off;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
     a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T; a.ptiles = N * a.tiles_x * a.tiles_y;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
@@ -397,17 +461,25 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     a.ctiles = a.ntiles = 0;
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    return fuse_pool2 ? launch_halo2<true>(a, s) : launch_halo2<false>(a, s);
+    if (gmax) return fuse_pool2 ? launch_halo2<true, true>(a, s) : launch_halo2<false, true>(a, s);
+    return fuse_pool2 ? launch_halo2<true, false>(a, s) : launch_halo2<false, false>(a, s);
 }
 
 extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
                                   int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
-    return halo2_dispatch(in, wgt, bias, nullptr, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+    return halo2_dispatch(in, wgt, bias, nullptr, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+}
+
+extern "C" int cvpce_conv3x3_halo_mac(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                                      int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad,
+                                      int fuse_pool2, void* stream) {
+    if (!mac) return CVPCE_ERR_ARG;
+    return halo2_dispatch(in, wgt, bias, nullptr, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, 1, fuse_pool2, stream);
 }
 
 extern "C" int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
                                          void* out, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad,
                                          int relu, void* stream) {
     if (!mask) return CVPCE_ERR_ARG;
-    return halo2_dispatch(in, wgt, bias, mask, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
+    return halo2_dispatch(in, wgt, bias, mask, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
 }

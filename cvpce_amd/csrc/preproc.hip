@@ -66,6 +66,8 @@ extern "C" int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, in
 // One block row per (crop, output row); boxes are read on the device (no host sync).
 // mode 0: f32 NCHW in [0,1] (the reference's `resize_for_classification` output)
 // mode 1: bf16 NHWC8, scale_to_tanh + MACVGG normalisation fused
+// mode 2: the same values as bf16 NHWC4 (8 bytes per pixel: half the bytes written here and read back by the fused VGG
+//         stem, which takes 4- or 8-channel pixels)
 __global__ void crop_resize_kernel(const float* __restrict__ img, const float* __restrict__ boxes,
                                    const int* __restrict__ count, void* __restrict__ out, int H0, int W0, int S,
                                    int mode, float m0, float m1, float m2, float s0, float s1, float s2) {
@@ -112,19 +114,24 @@ __global__ void crop_resize_kernel(const float* __restrict__ img, const float* _
         for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = f32_to_bf16((v[c] * 2.f - 1.f - mean[c]) / stdv[c]);
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (((size_t)p * S + oy) * S + ox) * 8) = o;
+        if (mode == 1) {
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (((size_t)p * S + oy) * S + ox) * 8) = o;
+        } else {
+            const bf16x4 o4 = {o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + (((size_t)p * S + oy) * S + ox) * 4) = o4;
+        }
     }
 }
 
 extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
                                  int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream) {
     if (!img || !boxes || !out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
-    if (mode == 1 && (!mean3 || !std3)) return CVPCE_ERR_ARG;
+    if (mode < 0 || mode > 2 || (mode != 0 && (!mean3 || !std3))) return CVPCE_ERR_ARG;
     if (max_boxes <= 0) return CVPCE_OK;
     if (max_boxes > 65535) return CVPCE_ERR_ARG;
     dim3 grid((S + 127) / 128, S, max_boxes);
     float m[3] = {0, 0, 0}, s[3] = {1, 1, 1};
-    if (mode == 1) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; s[i] = std3[i]; }
+    if (mode != 0) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; s[i] = std3[i]; }
     hipLaunchKernelGGL(crop_resize_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, out, H0, W0,
                        S, mode, m[0], m[1], m[2], s[0], s[1], s[2]);
     return cvpce_check_launch();

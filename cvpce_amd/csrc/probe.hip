@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const bf16_t* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)   // in-place accumulate, pinned by asm: the compiler otherwise rotates the loop-carried accumulators through copies
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));   // 256 accumulator registers: AGPRs
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const bf16_t* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)

@@ -89,13 +89,26 @@ class MACVGGEngine:
         CU count so that the persistent kernels' tile counts stay whole multiples of their grid)."""
         outs, outs_bf = [], []
         step = batch or MAX_EMBED_BATCH
+        plan = self.plan + [('desc', None)]            # the second descriptor: amax of the last map (classification.py:48-49)
         for s in range(0, x.shape[0], step):
             xb = x[s:s + step]
-            desc = torch.empty((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)
+            desc = torch.zeros((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)   # (zeros: the fused MAC epilogue takes atomic maxima of values >= 0)
             off = 0
             if self.stem is not None:
                 xb = ops.vgg_stem(xb, self.stem)
-            for kind, pc in self.plan:
+            i = 0
+            while i < len(plan):
+                kind, pc = plan[i]
+                nxt = plan[i + 1][0] if i + 1 < len(plan) else None
+                if kind == 'conv' and nxt == 'desc' and ops.can_fuse_mac(xb, pc):
+                    # conv + ReLU with the MAC descriptor taken in its epilogue; the map itself is stored only if something
+                    # reads it: pooled when MaxPool2d(2,2) follows (conv4_3 -> pool4), not at all at the end (conv5_3)
+                    after = plan[i + 2][0] if i + 2 < len(plan) else None
+                    fuse_pool = after == 'pool' and xb.shape[1] % 2 == 0 and xb.shape[2] % 2 == 0
+                    xb = ops.conv2d_relu_mac(xb, pc, desc, off, store=after is not None, pool=fuse_pool)
+                    off += pc.cout
+                    i += 3 if fuse_pool else 2
+                    continue
                 if kind == 'conv':
                     xb = ops.conv2d(xb, pc, act=1)
                 elif kind == 'conv_pool':
@@ -105,7 +118,7 @@ class MACVGGEngine:
                 else:
                     ops.global_max_into(xb, desc, off)
                     off += xb.shape[3]
-            ops.global_max_into(xb, desc, off)
+                i += 1
             r = ops.l2_normalize(desc, eps, want_bf16)
             if want_bf16:
                 outs.append(r[0]); outs_bf.append(r[1])

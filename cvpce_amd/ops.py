@@ -167,6 +167,38 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     return out
 
 
+USE_FUSED_MAC = True   # A/B switch: MAC descriptor (+ pool4, + no store of conv5_3) fused into the conv epilogue
+
+
+def can_fuse_mac(x, pc):
+    """The halo kernel's fused-MAC epilogue covers 3x3 / s1 / p1 layers with Cin % 64 == 0 and Cout > 128 (VGG16 conv4_3, conv5_3)."""
+    n, h, w, _ = x.shape
+    return (USE_FUSED_MAC and USE_HALO_3X3 and not FORCE_GENERIC_CONV and pc.cin_pad % 64 == 0 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1
+            and pc.pad == 1 and pc.cout % 8 == 0 and pc.cout > 128 and n * h * w * pc.cin_pad * 2 < 2 ** 32)
+
+
+def conv2d_relu_mac(x, pc, mac, mac_off, store=True, pool=False):
+    """relu(conv3x3(x)) with `mac[:, mac_off:mac_off+Cout] = amax over H, W` taken in the epilogue (classification.py:46-49).
+    `mac` (N, D) f32 must be zero-filled.  store=False: the map is not written at all (returns None); pool=True: the
+    returned map is MaxPool2d(2,2) of it (the descriptor is still over the unpooled map)."""
+    _need_cuda(x, mac)
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mac.dtype == torch.float32 and mac.is_contiguous()
+    assert can_fuse_mac(x, pc) and mac.shape[0] == x.shape[0] and mac_off + pc.cout <= mac.shape[1]
+    n, h, w, cin = x.shape
+    out = None
+    if store:
+        out = torch.empty((n, h // 2, w // 2, pc.cout) if pool else (n, h, w, pc.cout), dtype=BF16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.conv3x3_halo_mac(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(pool and store))
+    if prof is not None:
+        e1.record()
+        prof.records.append(('conv3x3_halo2_kernel', 2.0 * n * h * w * pc.cout * 9 * pc.cin, e0, e1))
+    return out
+
+
 class PackedStem:
     """Weights of conv3x3(3->64) + conv3x3(64->64) in the layout of cvpce_vgg_stem_fused (include/cvpce_amd.h)."""
 
@@ -268,14 +300,16 @@ MAX_CROPS_PER_LAUNCH = 65535
 
 
 def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, out=None):
-    """img (3,H0,W0) f32, boxes (P,4) f32 xyxy (device) -> (P,3,S,S) f32 [mode 0] | (P,S,S,8) bf16 [mode 1]."""
+    """img (3,H0,W0) f32, boxes (P,4) f32 xyxy (device) -> (P,3,S,S) f32 [mode 0] | (P,S,S,8) bf16 [mode 1] | (P,S,S,4) bf16
+    [mode 2: the 8-byte pixels the fused VGG stem reads; half the bytes of mode 1]."""
     _need_cuda(img, boxes)
     assert img.dtype == torch.float32 and img.is_contiguous()
     boxes = boxes.to(torch.float32).contiguous()
     p = boxes.shape[0]
     if out is None:
         out = (torch.empty((p, 3, size, size), dtype=torch.float32, device=img.device) if mode == 0
-               else torch.empty((p, size, size, 8), dtype=BF16, device=img.device))
+               else torch.empty((p, size, size, 8 if mode == 1 else 4), dtype=BF16, device=img.device))
+    assert out.shape[-1] == {0: size, 1: 8, 2: 4}[mode]
     m = [float(v) for v in mean] if mean is not None else None
     s = [float(v) for v in std] if std is not None else None
     for start in range(0, p, MAX_CROPS_PER_LAUNCH):

@@ -216,9 +216,11 @@ class BatchedPipeline:
         dpi = self.detector.detections_per_img
         size = datautils.CLASSIFICATION_IMAGE_SIZE
         n = len(images)
-        crops = torch.empty((n * dpi, size, size, 8), dtype=torch.bfloat16, device=eng.device)
+        # the fused VGG stem reads 4- or 8-channel pixels: 8-byte pixels halve what the crop kernel writes and the stem re-reads
+        narrow = getattr(emb_eng, 'stem', None) is not None
+        crops = torch.empty((n * dpi, size, size, 4 if narrow else 8), dtype=torch.bfloat16, device=eng.device)
         for i, img in enumerate(images):
-            ops.crop_resize(img, boxes[i], size, mode=1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
+            ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
                             std=getattr(self.classifier.encoder, 'input_std', TANH_STD), count=conf_count[i:i + 1],
                             out=crops[i * dpi:(i + 1) * dpi])
         # the embedder only runs over the valid crops (compaction = a gather of row indices)

@@ -64,6 +64,14 @@ def _conv3x3_halo(x, weight, bias, out, cout, k_pad, cout_pad, relu, pool):
           'cvpce_conv3x3_halo')
 
 
+@_op('conv3x3_halo_mac(Tensor x, Tensor weight, Tensor? bias, Tensor(a!)? out, Tensor(b!) mac, int mac_off, int cout, int k_pad, '
+     'int cout_pad, int pool) -> ()')
+def _conv3x3_halo_mac(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, pool):
+    n, h, w, cin = x.shape
+    check(lib.cvpce_conv3x3_halo_mac(_p(x), _p(weight), _p(bias), _p(out), _p(mac), mac.shape[1], mac_off, n, h, w, cin, cout, k_pad,
+                                     cout_pad, pool, _stream()), 'cvpce_conv3x3_halo_mac')
+
+
 @_op('conv3x3_halo_masked(Tensor x, Tensor weight, Tensor? bias, Tensor mask, Tensor(a!) out, int cout, int k_pad, int cout_pad, '
      'int relu) -> ()')
 def _conv3x3_halo_masked(x, weight, bias, mask, out, cout, k_pad, cout_pad, relu):

@@ -71,6 +71,15 @@ int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void*
  * fragment is fetched once and feeds 16 MFMAs. */
 int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                             int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+/* cvpce_conv3x3_halo (ReLU on, Cout > 128) with the MAC descriptor of classification.py:46-49 fused into the epilogue:
+ * mac[n * mac_stride + mac_off + c] = max over the post-ReLU output map of image n, channel c -- exactly
+ * `x.amax(dim=(-2, -1))` of the bf16 map the convolution would store (rounding is monotonic).  `mac` must be zero-filled
+ * by the caller (values are >= 0; the kernel takes an atomic max per tile).  `out` may be NULL: the map itself is then
+ * never written (VGG16 conv5_3, whose only consumer is the descriptor); with fuse_pool2 = 1 `out` receives
+ * MaxPool2d(2,2) of the map (conv4_3 feeding pool4), the descriptor is still taken over the unpooled map. */
+int cvpce_conv3x3_halo_mac(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                           int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int fuse_pool2,
+                           void* stream);
 /* cvpce_conv3x3_halo on a LEVEL ATLAS: several feature maps that share the conv weights (the 5 FPN levels under the
  * RetinaNet head, torchvision RetinaNetHead reached from cvpce/models/proposals.py:166) are packed side by side into one
  * [N][H][W][Cin] canvas with >= 1 zero pixel between them; mask is [H][W] bytes, 1 on level pixels, 0 on the gaps.
@@ -103,7 +112,8 @@ int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h
 /* production.py:20 + datautils.py:234-239: crop boxes (xyxy f32, truncated like .to(long)) from the
  * original image, pad to square with 0.5, bilinear resize to SxS.  Boxes p >= *count_dev are skipped
  * (count_dev may be NULL).  mode 0: f32 NCHW in [0,1]; mode 1: NHWC8 bf16 with scale_to_tanh
- * (utils.py:280) and the MACVGG normalisation (classification.py:41-44) fused.  mean3/std3 [host]. */
+ * (utils.py:280) and the MACVGG normalisation (classification.py:41-44) fused; mode 2: the same as NHWC4 bf16 (8-byte
+ * pixels, channel 3 zero: the input layout of cvpce_vgg_stem_fused with in_cstride = 4).  mean3/std3 [host]. */
 int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
                       int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream);
 /* (B,3,S,S) f32 NCHW -> NHWC8 bf16: optional x*2-1, then (x-mean)/std (Classifier.classify / build_index input) */

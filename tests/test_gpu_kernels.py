@@ -562,3 +562,48 @@ def test_conv3x3_full_size_linearity(cuda, name, n, cin, hw, cout, pool):
         if pool:
             ref = F.max_pool2d(ref, 2, 2)
         assert rel_err(nchw(y1[img:img + 1]), ref) < 1e-2
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,pool,store', [(5, 128, 32, 32, 512, True, True), (3, 64, 16, 16, 512, False, False),
+                                                        (2, 64, 40, 24, 256, False, True), (2, 64, 21, 19, 264, False, False)])
+def test_conv_mac_fused_equals_unfused(cuda, n, cin, h, w, cout, pool, store):
+    """MAC descriptor (classification.py:46-49 amax over H, W) taken in the conv epilogue -- with MaxPool2d(2,2) fused into the
+    store (conv4_3 -> pool4) or no store at all (conv5_3) -- against conv -> global-max kernel -> max-pool kernel: bit for bit,
+    ragged tiles and a ragged cout tile included; and against the oracle ops."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = r16(torch.randn(n, cin, h, w, generator=g))
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
+    xd = nhwc(x).to(cuda)
+    ops.HALO_RAGGED = True
+    try:
+        y = ops.conv2d(xd, pc, act=1)
+        want_mac = torch.zeros(n, 40 + cout, device=cuda)
+        ops.global_max_into(y, want_mac, 40)
+        mac = torch.zeros(n, 40 + cout, device=cuda)
+        got = ops.conv2d_relu_mac(xd, pc, mac, 40, store=store, pool=pool)
+    finally:
+        ops.HALO_RAGGED = False
+    torch.cuda.synchronize()
+    assert torch.equal(mac, want_mac) and float(mac[:, :40].abs().max()) == 0.0
+    if not store:
+        assert got is None
+    elif pool:
+        assert torch.equal(got, ops.maxpool2d(y, 2, 2))
+    else:
+        assert torch.equal(got, y)
+    ref = F.relu(F.conv2d(x, r16(wgt), bias, padding=1))
+    assert rel_err(mac[:, 40:].cpu(), r16(ref).amax(dim=(-2, -1))) < 1e-2
+
+
+def test_crop_resize_narrow_pixels(cuda):
+    """Crop mode 2 (8-byte NHWC4 pixels for the fused stem) carries exactly the values of mode 1 (NHWC8)."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import classification as C
+    img = torch.rand(3, 300, 420, generator=torch.Generator().manual_seed(8)).to(cuda)
+    boxes = torch.tensor([[10.2, 20.7, 200.1, 180.0], [0., 0., 420., 300.], [399.5, 250.2, 460.0, 330.0]], device=cuda)
+    a = ops.crop_resize(img, boxes, 256, mode=1, mean=C.TANH_MEAN, std=C.TANH_STD)
+    b = ops.crop_resize(img, boxes, 256, mode=2, mean=C.TANH_MEAN, std=C.TANH_STD)
+    assert b.shape == (3, 256, 256, 4) and torch.equal(a[..., :4], b) and float(a[..., 3:].abs().max()) == 0.0
