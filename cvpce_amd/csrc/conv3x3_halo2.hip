@@ -57,6 +57,9 @@ struct Halo2Args {
     const float* bias;
     const unsigned char* mask;   // optional [H][W]: output pixels with mask 0 are stored as zeros (atlas gaps); not with POOL
     bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]; null with gmax: nothing is stored (conv5_3)
+    const int* tile_map; // optional: the pixel tiles to compute, (ty << 16) | tx, the same list for every image (level atlas:
+                         // tiles that lie wholly in a gap are skipped; their outputs keep the zeros the buffer was created with)
+    int tiles_per_image; // entries of tile_map (with a map), else tiles_x * tiles_y
     float* gmax;         // optional MAC descriptor [N][gmax_stride]: gmax[n][gmax_off + co] = max over the map (relu = 1)
     int gmax_stride, gmax_off;
     int N, H, W, Cin, Cout, K_pad, relu;
@@ -89,10 +92,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         const int t = lbid + seq * (int)gridDim.x;
         ct = t % a.ctiles;
         const int p = t / a.ctiles;
-        n = p / (a.tiles_x * a.tiles_y);
-        const int r = p - n * (a.tiles_x * a.tiles_y);
-        ty = r / a.tiles_x;
-        tx = r - ty * a.tiles_x;
+        n = p / a.tiles_per_image;
+        const int r = p - n * a.tiles_per_image;
+        if (a.tile_map) {
+            const int packed = a.tile_map[r];
+            ty = packed >> 16;
+            tx = packed & 0xFFFF;
+        } else {
+            ty = r / a.tiles_x;
+            tx = r - ty * a.tiles_x;
+        }
     };
 
     // ---- patch DMA: piece j fills patch rows 8j .. 8j+7 (row = lane>>3, phys chunk = lane&7); pieces dealt
@@ -436,12 +445,14 @@ static int launch_halo2(Halo2Args a, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
-static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out, float* gmax,
+static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, const int* tile_map,
+                          int n_map, void* out, float* gmax,
                           int gmax_stride, int gmax_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
                           int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || (!out && !gmax)) return CVPCE_ERR_ARG;
     if (gmax && (!relu || mask || Cout <= 128 || gmax_off < 0 || gmax_off + Cout > gmax_stride)) return CVPCE_ERR_ARG;
+    if (tile_map && (!mask || n_map <= 0)) return CVPCE_ERR_ARG;
     if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
     if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
     if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
@@ -455,7 +466,9 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = mask; a.out = (bf16_t*)out;
     a.gmax = gmax; a.gmax_stride = gmax_stride; a.gmax_off = gmax_off;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
-    a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T; a.ptiles = N * a.tiles_x * a.tiles_y;
+    a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T;
+    a.tile_map = tile_map; a.tiles_per_image = tile_map ? n_map : a.tiles_x * a.tiles_y;
+    a.ptiles = N * a.tiles_per_image;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;
@@ -467,19 +480,19 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
 
 extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
                                   int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
-    return halo2_dispatch(in, wgt, bias, nullptr, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+    return halo2_dispatch(in, wgt, bias, nullptr, nullptr, 0, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
 }
 
 extern "C" int cvpce_conv3x3_halo_mac(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
                                       int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad,
                                       int fuse_pool2, void* stream) {
     if (!mac) return CVPCE_ERR_ARG;
-    return halo2_dispatch(in, wgt, bias, nullptr, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, 1, fuse_pool2, stream);
+    return halo2_dispatch(in, wgt, bias, nullptr, nullptr, 0, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, 1, fuse_pool2, stream);
 }
 
 extern "C" int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
-                                         void* out, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad,
-                                         int relu, void* stream) {
+                                         const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout,
+                                         int K_pad, int Cout_pad, int relu, void* stream) {
     if (!mask) return CVPCE_ERR_ARG;
-    return halo2_dispatch(in, wgt, bias, mask, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
+    return halo2_dispatch(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
 }

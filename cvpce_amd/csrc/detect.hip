@@ -5,16 +5,19 @@
 // consumed at /root/reference/cvpce/production.py:13-15.
 //
 //   decode_topk  one 1024-thread workgroup per (level, image): sigmoid +
-//                score threshold, exact top-k by 4-pass LDS radix select,
+//                score threshold, exact top-k by 4-pass LDS radix select (8 loads
+//                in flight per thread, wave-aggregated histogram atomics),
 //                LDS bitonic sort of the <=1024 survivors, anchor synthesis +
 //                box decode + clip.
 //   nms_sort     one workgroup per image: merge the levels, LDS bitonic sort
 //                of <=8192 candidates by (logit desc, position asc).
 //   nms_mask     64x64 IoU bit-matrix tiles (upper triangle), one wave per tile.
-//   nms_scan     one wave per image: 64-box chunks; in-chunk dependencies via
-//                v_readlane on the diagonal words, cross-chunk via OR of the
-//                kept rows; early exit at detections_per_img; rescale to the
-//                original image, count the score > confidence prefix.
+//   nms_scan     one workgroup per image: 64-box chunks; in-chunk dependencies
+//                by one wave (v_readlane on the diagonal words, jumping from
+//                survivor to survivor), cross-chunk by all 16 waves OR-ing the
+//                kept rows (8 independent row loads per thread); early exit at
+//                detections_per_img; rescale to the original image, count the
+//                score > confidence prefix.
 //
 // Ordering rule: the reference sorts on sigmoid scores with an unstable sort,
 // leaving ties unspecified.  Here every ordering uses the fp32 *logit* (a
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
     __shared__ unsigned long long sel[1024];
     __shared__ int hist[256];
     __shared__ int wtot[16];
-    __shared__ int s_cnt, s_prefix, s_need, s_nsel, s_eqbase;
+    __shared__ int s_cnt, s_prefix, s_need, s_nsel, s_eqbase, s_eqtotal;
 
     const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const int gh = a.gh[level], gw = a.gw[level];
@@ -77,15 +80,25 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
     const float* lg = a.logits[level] + (size_t)img * n;
     const float* rg = a.regs[level] + (size_t)img * (size_t)(gh * gw * a.A) * 4;
 
-    if (tid == 0) { s_cnt = 0; s_nsel = 0; s_eqbase = 0; }
+    if (tid == 0) { s_cnt = 0; s_nsel = 0; s_eqbase = 0; s_eqtotal = 0; }
     sel[tid] = 0ull;
     __syncthreads();
+    // Every pass over the level's logits keeps UNROLL independent loads in flight per thread (a dependent-load loop spends
+    // ~0.5 us per iteration on the P3 level's 88 iterations) and evaluates the score test exactly as the oracle does.
+    constexpr int UNROLL = 8;
+    const int lane = tid & 63;
     // count candidates above the score threshold
     int local = 0;
-    for (int i = tid; i < n; i += 1024) local += (sigmoidf_ref(lg[i]) > a.score_thresh) ? 1 : 0;
+    for (int base = 0; base < n; base += UNROLL * 1024) {
+        float v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { const int i = base + u * 1024 + tid; v[u] = i < n ? lg[i] : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) local += (sigmoidf_ref(v[u]) > a.score_thresh) ? 1 : 0;   // sigmoid(-inf) = 0
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
-    if ((tid & 63) == 0) atomicAdd(&s_cnt, local);
+    if (lane == 0) atomicAdd(&s_cnt, local);
     __syncthreads();
     const int cnt = s_cnt;
     const int k = cnt < a.topk ? cnt : a.topk;
@@ -98,11 +111,27 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += 1024) {
-                float l = lg[i];
-                if (sigmoidf_ref(l) > a.score_thresh) {
-                    unsigned key = ordered_key(l);
-                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            for (int base = 0; base < n; base += UNROLL * 1024) {
+                float v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) { const int i = base + u * 1024 + tid; v[u] = i < n ? lg[i] : -INFINITY; }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned key = ordered_key(v[u]);
+                    const bool pred = (sigmoidf_ref(v[u]) > a.score_thresh) && ((key & mask) == prefix);
+                    const unsigned bin = (key >> shift) & 255u;
+                    // wave-aggregated histogram update: the lanes that share the first active lane's bin are counted by ONE
+                    // LDS atomic (on the leading digits nearly every key of a level falls into the same two or three bins,
+                    // and 64 lanes hitting one bin serialise), the others add individually
+                    const unsigned long long act = __ballot(pred);
+                    if (act) {
+                        const int leader = __ffsll((long long)act) - 1;
+                        const unsigned lb = (unsigned)__shfl((int)bin, leader);
+                        const bool same = pred && bin == lb;
+                        const unsigned long long sm = __ballot(same);
+                        if (lane == leader) atomicAdd(&hist[lb], __popcll(sm));
+                        if (pred && !same) atomicAdd(&hist[bin], 1);
+                    }
                 }
             }
             __syncthreads();
@@ -114,6 +143,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
                 }
                 s_prefix = (int)(prefix | ((unsigned)b << shift));
                 s_need = need - cum;
+                s_eqtotal = hist[b];          // after the last pass: how many candidates carry exactly the key T
             }
             __syncthreads();
             prefix = (unsigned)s_prefix;
@@ -124,22 +154,38 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
         T = prefix;
         need_eq = need;
     }
-    // ordered compaction: key > T always; key == T for the first need_eq in index order
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        bool valid = false, gt = false, eq = false;
-        unsigned key = 0;
-        if (i < n) {
-            float l = lg[i];
-            valid = sigmoidf_ref(l) > a.score_thresh;
-            key = ordered_key(l);
-            if (cnt > k) { gt = valid && key > T; eq = valid && key == T; }
-            else gt = valid;
+    if (cnt <= k || need_eq == s_eqtotal) {
+        // every candidate with key >= T is taken (all ties at T fit): the order of arrival is irrelevant, the bitonic sort
+        // below orders by (key, index)
+        for (int base = 0; base < n; base += UNROLL * 1024) {
+            float v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { const int i = base + u * 1024 + tid; v[u] = i < n ? lg[i] : -INFINITY; }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int i = base + u * 1024 + tid;
+                const unsigned key = ordered_key(v[u]);
+                if ((sigmoidf_ref(v[u]) > a.score_thresh) && (cnt <= k || key >= T)) {
+                    const int pos = atomicAdd(&s_nsel, 1);
+                    if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+                }
+            }
         }
-        bool take = gt;
-        if (cnt > k) {
+    } else {
+        // more candidates tie at the key T than fit: take the first need_eq of them in index order (ordered compaction)
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + tid;
+            bool valid = false, gt = false, eq = false;
+            unsigned key = 0;
+            if (i < n) {
+                float l = lg[i];
+                valid = sigmoidf_ref(l) > a.score_thresh;
+                key = ordered_key(l);
+                gt = valid && key > T; eq = valid && key == T;
+            }
+            bool take = gt;
             unsigned long long bal = __ballot(eq);
-            int lane = tid & 63, w = tid >> 6;
+            int w = tid >> 6;
             int pre = __popcll(bal & ((1ull << lane) - 1ull));
             if (lane == 0) wtot[w] = __popcll(bal);
             __syncthreads();
@@ -153,10 +199,10 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
                 s_eqbase += t;
             }
             __syncthreads();
-        }
-        if (take) {
-            int pos = atomicAdd(&s_nsel, 1);
-            if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            if (take) {
+                int pos = atomicAdd(&s_nsel, 1);
+                if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            }
         }
     }
     __syncthreads();
@@ -298,54 +344,82 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsArgs a) {
     a.mask[((size_t)img * a.Tmax + i) * a.words + cb] = bits;
 }
 
-__global__ __launch_bounds__(64) void nms_scan_kernel(NmsArgs a) {
-    const int img = blockIdx.x, lane = threadIdx.x;
+// Greedy scan over the IoU bit matrix, one 1024-thread workgroup per image.  The chunk-to-chunk dependency is serial by
+// nature (a box survives iff no KEPT higher-ranked box suppresses it), so the work per 64-box chunk is kept short:
+//   * wave 0 resolves the chunk: instead of visiting all 64 boxes it jumps from one surviving box to the next
+//     (`avail` = not yet suppressed), OR-ing that box's diagonal word into the suppressed set -- as many steps as boxes are
+//     kept in the chunk (a handful), the diagonal words fetched with v_readlane at a scalar index;
+//   * all 16 waves then OR the kept rows into the removed-bits of the later words: thread (g, w) owns word w and the kept
+//     boxes 8g .. 8g+7 of the chunk, issues its 8 row loads together (independent, coalesced over w) and merges with one
+//     LDS atomic OR -- the one-wave version fetched the kept rows one after the other, ~0.5 us of L2 latency each.
+__global__ __launch_bounds__(1024) void nms_scan_kernel(NmsArgs a) {
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.s_total[img];
     const int nw = (T + 63) / 64;
     __shared__ int keep[SORT_CAP];
-    unsigned long long rem0 = 0ull, rem1 = 0ull;   // removed words `lane` and `lane + 64`
-    int nkept = 0;
+    __shared__ unsigned long long rem[SORT_CAP / 64];      // removed bits per 64-box word
+    __shared__ unsigned long long s_kept;
+    __shared__ int s_nkept;
+    if (tid < SORT_CAP / 64) rem[tid] = 0ull;
+    if (tid == 0) s_nkept = 0;
+    __syncthreads();
     const unsigned long long* M = a.mask + (size_t)img * a.Tmax * a.words;
-    for (int b = 0; b < nw && nkept < a.max_keep; ++b) {
-        unsigned long long src = (b < 64) ? rem0 : rem1;
-        unsigned long long cur = __shfl(src, b & 63);
-        const int row = b * 64 + lane;
-        unsigned long long diag = (row < T) ? M[(size_t)row * a.words + b] : 0ull;
-        const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
-        const int rows_here = (T - b * 64) < 64 ? (T - b * 64) : 64;
-        unsigned long long kept = 0ull;
+    const int w = tid & 127, g = tid >> 7;                // word owned in the propagation step, group of 8 chunk rows
+    for (int b = 0; b < nw; ++b) {
+        if (wave == 0) {
+            const int row = b * 64 + lane;
+            const unsigned long long diag = (row < T) ? M[(size_t)row * a.words + b] : 0ull;
+            const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
+            const int rows_here = (T - b * 64) < 64 ? (T - b * 64) : 64;
+            const unsigned long long valid = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+            unsigned long long cur = rem[b];                // uniform
+            unsigned long long kept = 0ull;
+            unsigned long long avail = ~cur & valid;
+            while (avail) {
+                const int kk = __ffsll((long long)avail) - 1;
+                kept |= 1ull << kk;
+                const unsigned lo = __builtin_amdgcn_readlane(dlo, kk), hi = __builtin_amdgcn_readlane(dhi, kk);
+                cur |= ((unsigned long long)hi << 32) | lo;   // the diagonal word holds only bits above kk
+                avail = ~cur & valid & ~((2ull << kk) - 1ull);
+            }
+            const int nkept = s_nkept;
+            if ((kept >> lane) & 1ull) {
+                const int pos = nkept + __popcll(kept & ((1ull << lane) - 1ull));
+                if (pos < SORT_CAP) keep[pos] = row;
+            }
+            if (lane == 0) { s_kept = kept; s_nkept = nkept + __popcll(kept); }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        if (s_nkept >= a.max_keep) break;
+        // propagate the kept rows of this chunk to the later words
+        if (w > b && w < nw) {
+            const unsigned sub = (unsigned)(kept >> (8 * g)) & 0xFFu;
+            if (sub) {
+                unsigned long long v[8];
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) {
-            const unsigned lo = __builtin_amdgcn_readlane(dlo, kk), hi = __builtin_amdgcn_readlane(dhi, kk);
-            if (kk < rows_here && !((cur >> kk) & 1ull)) {
-                kept |= (1ull << kk);
-                cur |= ((unsigned long long)hi << 32) | lo;
+                for (int j = 0; j < 8; ++j) {
+                    int r = b * 64 + 8 * g + j;
+                    r = r < T ? r : T - 1;                  // (rows past the end are never kept: the value is masked below)
+                    v[j] = M[(size_t)r * a.words + w];
+                }
+                unsigned long long acc = 0ull;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc |= ((sub >> j) & 1u) ? v[j] : 0ull;
+                if (acc) atomicOr(&rem[w], acc);
             }
         }
-        // record kept indices in order
-        if ((kept >> lane) & 1ull) {
-            int pos = nkept + __popcll(kept & ((1ull << lane) - 1ull));
-            if (pos < SORT_CAP) keep[pos] = row;
-        }
-        nkept += __popcll(kept);
-        if (nkept >= a.max_keep) break;
-        // propagate the kept rows to the later words
-        const int w0 = lane, w1 = lane + 64;
-        const bool use0 = (w0 > b) && (w0 < nw), use1 = (w1 > b) && (w1 < nw);
-        unsigned long long kb = kept;
-        while (kb) {
-            const int k0 = __ffsll((long long)kb) - 1;
-            kb &= kb - 1ull;
-            const unsigned long long* r = M + (size_t)(b * 64 + k0) * a.words;
-            if (use0) rem0 |= r[w0];
-            if (use1) rem1 |= r[w1];
-        }
+        __syncthreads();
     }
     __syncthreads();
+    const int nkept = s_nkept;
     const int nout = nkept < a.max_keep ? nkept : a.max_keep;
     const float rh = a.ratios[img * 2 + 0], rw = a.ratios[img * 2 + 1];
+    __shared__ int s_conf;
+    if (tid == 0) s_conf = 0;
+    __syncthreads();
     int nconf = 0;
-    for (int r = lane; r < nout; r += 64) {
+    for (int r = tid; r < nout; r += 1024) {
         const size_t src = (size_t)img * a.Tmax + keep[r];
         const float4 bx = *reinterpret_cast<const float4*>(a.s_boxes + src * 4);
         const size_t dst = (size_t)img * a.max_keep + r;
@@ -357,7 +431,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(NmsArgs a) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nconf += __shfl_xor(nconf, off);
-    if (lane == 0) { a.out_count[img] = nout; a.out_conf_count[img] = nconf; }
+    if (lane == 0 && nconf) atomicAdd(&s_conf, nconf);
+    __syncthreads();
+    if (tid == 0) { a.out_count[img] = nout; a.out_conf_count[img] = s_conf; }
 }
 
 extern "C" size_t cvpce_detect_workspace_bytes(int N, int L, int topk) {
@@ -434,6 +510,6 @@ extern "C" int cvpce_detect_postprocess(const float* const* logits, const float*
     }
     hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(1024), SORT_CAP * 8, s, n);
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, N), dim3(64), 0, s, n);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(64), 0, s, n);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(1024), 0, s, n);
     return cvpce_check_launch();
 }

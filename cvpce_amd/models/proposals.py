@@ -355,35 +355,44 @@ class GLNEngine:
             mask = torch.zeros(hc, wc, dtype=torch.uint8)
             for (h, w), (oy, ox) in zip(shapes, offs):
                 mask[oy:oy + h, ox:ox + w] = 1
-            cache[key] = (hc, wc, offs, mask.to(self.device))
-        hc, wc, offs, mask = cache[key]
-        atlas = torch.zeros(n, hc, wc, feats[0].shape[3], dtype=feats[0].dtype, device=self.device)
+            cache[key] = (hc, wc, offs, mask.to(self.device), ops.atlas_tile_map(mask).to(self.device), int(mask.sum()))
+        hc, wc, offs, mask, tile_map, npix = cache[key]
+        # Atlas buffers live in the engine, zero-filled ONCE: the kernels write level pixels (and zeros on the gap pixels of
+        # the tiles they compute) and skip the tiles that lie wholly in a gap, so the gaps stay zero -- no memset, and about
+        # 1/7 of the canvas tiles (the empty ones) are never scheduled.
+        bufs = self.__dict__.setdefault('_atlas_bufs', {})
+        bkey = (n, hc, wc)
+        if bkey not in bufs:
+            if len(bufs) >= MAX_DETECT_GRAPHS:
+                bufs.pop(next(iter(bufs)))
+            bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=torch.bfloat16, device=self.device) for _ in range(5)]
+        atlas, cls_a, cls_b, reg_a, reg_b = bufs[bkey]
         for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
             atlas[:, oy:oy + h, ox:ox + w] = f
 
-        def chain(tower, final):
+        def chain(tower, final, ping, pong):
             t = atlas
             for pc in tower:
-                t = ops.conv3x3_atlas(t, pc, mask, act=1)
+                t = ops.conv3x3_atlas(t, pc, mask, act=1, tile_map=tile_map, out=ping, mask_pixels=npix)
+                ping, pong = pong, ping
             o = ops.conv2d(t, final, out_f32=True)           # gap pixels hold junk here; they are never read
             return [o[:, oy:oy + h, ox:ox + w].contiguous() for (h, w), (oy, ox) in zip(shapes, offs)]
 
         main = torch.cuda.current_stream()
         if not self.side_streams:
-            return chain(self.cls_tower, self.cls_out), chain(self.reg_tower, self.reg_out)
+            return chain(self.cls_tower, self.cls_out, cls_a, cls_b), chain(self.reg_tower, self.reg_out, reg_a, reg_b)
         # the two towers are independent: the second one runs on a side stream and fills the first one's tail
         side = self.side_streams[0]
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            reg = chain(self.reg_tower, self.reg_out)
+            reg = chain(self.reg_tower, self.reg_out, reg_a, reg_b)
             for r in reg:
                 r.record_stream(main)
-            atlas.record_stream(side)
             done = torch.cuda.Event()
             done.record(side)
-        cls = chain(self.cls_tower, self.cls_out)
+        cls = chain(self.cls_tower, self.cls_out, cls_a, cls_b)
         main.wait_event(done)
         return cls, reg
 

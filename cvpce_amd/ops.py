@@ -215,24 +215,38 @@ class PackedStem:
         self.flops_per_pixel = 2.0 * 64 * (27 + 576)
 
 
-def conv3x3_atlas(x, pc, mask, act=1):
+def atlas_tile_map(mask, tile=16):
+    """(H,W) uint8 level mask (host or device) -> int32 device tensor of the 16x16 tiles that contain a level pixel, (ty << 16) | tx."""
+    m = mask.cpu().bool()
+    h, w = m.shape
+    tiles = [(ty << 16) | tx for ty in range((h + tile - 1) // tile) for tx in range((w + tile - 1) // tile)
+             if bool(m[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile].any())]
+    return torch.tensor(tiles, dtype=torch.int32).to(mask.device)
+
+
+def conv3x3_atlas(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None):
     """3x3 / stride 1 / pad 1 conv over a LEVEL ATLAS x (N,H,W,Cin) bf16: several maps sharing `pc`, packed with zero
-    gaps; mask (H,W) uint8 is 1 on level pixels.  Output pixels on the gaps are written as zeros."""
-    _need_cuda(x, mask)
+    gaps; mask (H,W) uint8 is 1 on level pixels.  Output pixels on the gaps are written as zeros.  tile_map (atlas_tile_map):
+    only those tiles are computed -- `out` must then be given and hold zeros on the skipped (all-gap) tiles."""
+    _need_cuda(x, mask, tile_map, out)
     assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mask.dtype == torch.uint8 and mask.is_contiguous()
     n, h, w, cin = x.shape
     assert tuple(mask.shape) == (h, w) and cin == pc.cin_pad and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad == 1
-    assert pc.cin_pad % 64 == 0 and pc.cout % 8 == 0 and act in (0, 1)
-    out = torch.empty((n, h, w, pc.cout), dtype=BF16, device=x.device)
+    assert pc.cin_pad % 64 == 0 and pc.cout % 8 == 0 and pc.cout > 128 and act in (0, 1)
+    if tile_map is not None:
+        assert out is not None and tile_map.dtype == torch.int32 and tile_map.is_contiguous()
+    if out is None:
+        out = torch.empty((n, h, w, pc.cout), dtype=BF16, device=x.device)
+    assert tuple(out.shape) == (n, h, w, pc.cout) and out.dtype == BF16 and out.is_contiguous()
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    T.conv3x3_halo_masked(x, pc.weight, pc.bias, mask, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
+    T.conv3x3_halo_masked(x, pc.weight, pc.bias, mask, tile_map, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
     if prof is not None:
         e1.record()
-        prof.records.append(('conv3x3_halo2_kernel' ,
-                             2.0 * float(mask.sum().item()) * n * pc.cout * 9 * pc.cin, e0, e1))
+        npix = float(mask.sum().item()) if mask_pixels is None else float(mask_pixels)
+        prof.records.append(('conv3x3_halo2_kernel', 2.0 * npix * n * pc.cout * 9 * pc.cin, e0, e1))
     return out
 
 

@@ -72,12 +72,12 @@ def _conv3x3_halo_mac(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad,
                                      cout_pad, pool, _stream()), 'cvpce_conv3x3_halo_mac')
 
 
-@_op('conv3x3_halo_masked(Tensor x, Tensor weight, Tensor? bias, Tensor mask, Tensor(a!) out, int cout, int k_pad, int cout_pad, '
-     'int relu) -> ()')
-def _conv3x3_halo_masked(x, weight, bias, mask, out, cout, k_pad, cout_pad, relu):
+@_op('conv3x3_halo_masked(Tensor x, Tensor weight, Tensor? bias, Tensor mask, Tensor? tile_map, Tensor(a!) out, int cout, int k_pad, '
+     'int cout_pad, int relu) -> ()')
+def _conv3x3_halo_masked(x, weight, bias, mask, tile_map, out, cout, k_pad, cout_pad, relu):
     n, h, w, cin = x.shape
-    check(lib.cvpce_conv3x3_halo_masked(_p(x), _p(weight), _p(bias), _p(mask), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu,
-                                        _stream()), 'cvpce_conv3x3_halo_masked')
+    check(lib.cvpce_conv3x3_halo_masked(_p(x), _p(weight), _p(bias), _p(mask), _p(tile_map), tile_map.numel() if tile_map is not None else 0,
+                                        _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, _stream()), 'cvpce_conv3x3_halo_masked')
 
 
 @_op('vgg_stem_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out) -> ()')

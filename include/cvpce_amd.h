@@ -84,9 +84,12 @@ int cvpce_conv3x3_halo_mac(const void* in, const void* wgt, const float* bias, v
  * RetinaNet head, torchvision RetinaNetHead reached from cvpce/models/proposals.py:166) are packed side by side into one
  * [N][H][W][Cin] canvas with >= 1 zero pixel between them; mask is [H][W] bytes, 1 on level pixels, 0 on the gaps.
  * Outputs on mask-0 pixels are stored as zeros, so the result is again a valid atlas (the gaps ARE the next layer's
- * zero padding) and one launch replaces one launch per level. */
-int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask, void* out,
-                              int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu, void* stream);
+ * zero padding) and one launch replaces one launch per level.  tile_map (optional, device): the n_tiles 16x16-pixel tiles
+ * to compute, (ty << 16) | tx, the same list for every image -- tiles that lie wholly in a gap are left out and `out` must
+ * then already hold zeros there (the caller keeps zero-initialised atlas buffers). */
+int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                              const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
+                              int Cout_pad, int relu, void* stream);
 
 /* Upper bound on the workgroups the persistent convolution kernels launch (default 256 = one per CU).  A host that
  * runs them on a stream restricted to fewer CUs (hipExtStreamCreateWithCUMask) sets the bound to that CU count.

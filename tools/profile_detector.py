@@ -5,6 +5,7 @@ import torch
 from cvpce_amd import ops, synthetic
 import cvpce_amd.models.proposals as P
 P.N_SIDE_STREAMS = 0
+P.USE_DETECT_GRAPH = False
 dev = torch.device('cuda')
 det = synthetic.synthetic_gln(seed=0, detections_per_img=200).to(dev)
 imgs = [synthetic.shelf_image(i, 2048, 2048).to(dev) for i in range(8)]
@@ -38,5 +39,5 @@ for shp, cout, k, s, a, b, fl in recs:
     key = (shp[1:] if shp[0] != 'atlas' else shp, cout, k, s)
     d = agg.setdefault(key, [0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl
 print('sum conv ms', tot)
-for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print(f'{str(key):44s} x{n:2d} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF')
