@@ -14,14 +14,6 @@
 //     the 18 patch rows ONCE (ds_read_b128, immediate offsets, 4-deep register ring) and issues up to 6 MFMAs on it:
 //     108 fragment reads per chunk instead of 288 -- the reads were 21 % of conv4_2 (profiles/r01d_ablation_halo2.md).
 // Per chunk and wave: 6 steps x (18 ds_read_b128 + 96 MFMA 16x16x32 + 6 weight loads).
-//   * STAGGER: the two waves of a SIMD (w and w + 4) run the same program; in lock step they would reach their tile
-//     epilogues (VALU + stores, no MFMA) together and leave the matrix pipe idle -- the shallow-K layers lost 10-25 % to
-//     that (conv3_1 1340 vs conv4_2 1540 TFLOP/s).  Waves 4-7 therefore take the per-chunk hand-off (vmcnt wait, barrier,
-//     next patch DMA) after step 2 instead of step 5: the SAME barrier instance pairs "waves 0-3 at the end of chunk c"
-//     with "waves 4-7 in the middle of chunk c", which pins them half a chunk behind, so one half's epilogue always runs
-//     beside the other half's MFMA stream.  The hazards are unchanged: the DMA into the buffer of chunk c-1 is issued
-//     after a barrier every wave reaches with chunk c-1 behind it, and a chunk's patch is read only after a barrier
-//     every wave passed with its pieces landed (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
 // K order / weight layout: chunk-major [Cout_pad][K_pad] of include/cvpce_amd.h.  Fused bias / ReLU / MaxPool2d(2,2).
 #include "common.h"
 #include "../../include/cvpce_amd.h"
@@ -31,8 +23,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 // compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 no s_setprio around the MFMA
 // groups, 2 XCD-aware tile order, 4 no patch DMA in the loop, 8 no weight loads in the loop, 16 no output stores,
-// 32 no fragment reads in the loop, 64 no hand-off barrier (races: timing only), 128 no stagger (all waves hand off after
-// step 5: the pre-stagger schedule, results identical)
+// 32 no fragment reads in the loop, 64 no hand-off barrier (races: timing only), 256 (dispatch) 32-aligned maps to the wide kernel
 #ifndef CVPCE_DBG
 #define CVPCE_DBG 0
 #endif
@@ -235,19 +226,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         if (!(CVPCE_DBG & 64)) __builtin_amdgcn_s_barrier();                                                   \
         issue_next_patch();                                                                                    \
     }
-    // step T < 5: fetch the next step's weights, stream the rows; rows 16, 17 prefetch rows 0, 1 of step T + 1.
-    // HANDOFF: a wave-uniform condition -- the late half (waves 4-7) takes the chunk hand-off here, after step 2
-#define G2_STEP_H(T, HANDOFF)                                                                                  \
+    // step T < 5: fetch the next step's weights, stream the rows; rows 16, 17 prefetch rows 0, 1 of step T + 1
+#define G2_STEP(T)                                                                                             \
     {                                                                                                          \
         G2_LOAD_A((T) + 1, sb_cur)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         G2_ROWS_0_15(T)                                                                                        \
-        if (HANDOFF) G2_HANDOFF()                                                                              \
         G2_SET_E((T) + 1, bufb)                                                                                \
         G2_READ((T) + 1, 0) G2_ROW(T, 16)                                                                      \
         G2_READ((T) + 1, 1) G2_ROW(T, 17)                                                                      \
     }
-#define G2_STEP(T) G2_STEP_H(T, false)
 
     // ---- prologue ----
     int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct;
@@ -281,13 +269,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     G2_READ(0, 1)
 
     const int lp = lane & 15;
-    const bool late = (wc >= 4) && !(CVPCE_DBG & 128);   // the second-dispatched half: SIMD partners of waves 0-3 (128: no stagger)
     for (int cc = 0; cc < total_chunks; ++cc) {
         // keep the per-step address variants inside the loop: hoisted they cost VGPRs the accumulators need
         asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
-        G2_STEP(0) G2_STEP(1) G2_STEP_H(2, late) G2_STEP(3) G2_STEP(4)
-        // ---- last step of the chunk; the early half takes the chunk hand-off here, before rows 16, 17 prefetch from the
-        //      NEXT buffer (whose pieces the late half saw landed at its own hand-off, half a chunk ago) ----
+        G2_STEP(0) G2_STEP(1) G2_STEP(2) G2_STEP(3) G2_STEP(4)
+        // ---- last step of the chunk, with the chunk hand-off before its rows 16, 17 prefetch from the NEXT buffer ----
         {
             G2_LOAD_A(0, sb_next)        // step 0 of the next chunk (slot 0); past the last chunk a harmless reload
             __builtin_amdgcn_sched_barrier(0);
@@ -296,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
             // that the loop body has one shape and the accumulators stay in place.
             const int nbufi = (bufi == 2) ? 0 : bufi + 1;
             const unsigned nbufb = lds_a + (unsigned)nbufi * G2_A_BYTES;
-            if (!late) G2_HANDOFF()                      // chunk cc + 2 -> the buffer chunk cc - 1 used
+            G2_HANDOFF()                                 // chunk cc + 2 -> the buffer chunk cc - 1 used
             G2_SET_E(0, nbufb)
             G2_READ(0, 0) G2_ROW(5, 16)
             G2_READ(0, 1) G2_ROW(5, 17)
@@ -419,7 +405,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
 #undef G2_STEP
-#undef G2_STEP_H
 #undef G2_HANDOFF
 #undef G2_ROWS_0_15
 #undef G2_RP
@@ -460,7 +445,9 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31)) return CVPCE_ERR_ARG;
     if (mask && fuse_pool2) return CVPCE_ERR_ARG;
     // few output channels: the wide-tile kernel keeps every wave's 32-cout x 256-pixel tile (conv3x3_halo3.hip)
-    if (Cout <= 128 && !mask)
+    // (CVPCE_DBG & 256, dev A/B only: also route every map that 32-pixel-wide tiles cover exactly to the wide-tile kernel --
+    //  measured and not adopted, profiles/r02_ablation_halo2.md)
+    if ((Cout <= 128 || ((CVPCE_DBG & 256) && !gmax && W % 32 == 0 && H % 16 == 0)) && !mask)
         return cvpce_conv3x3_halo_wide(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
     Halo2Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = mask; a.out = (bf16_t*)out;

@@ -9,10 +9,7 @@
 //   * row streaming as in conv3x3_halo2.hip: a step fixes kw, holds the weights of the three taps (kh, kw) of the
 //     32-channel sub-chunk (6 loads of 64 B per row, straight from L2 into MFMA layout, one step ahead), reads each of
 //     the 18 patch rows once (ds_read_b128, immediate offsets) and issues up to 6 MFMA 16x16x32 on it,
-//   * one workgroup barrier per sub-chunk (3 steps); the loop body is one 64-channel chunk = two sub-chunks;
-//   * STAGGER (see conv3x3_halo2.hip): waves 4-7 -- the SIMD partners of waves 0-3 -- take the sub-chunk hand-off after
-//     steps 0 and 3 instead of 2 and 5, which pins them two steps behind: one half's tile epilogue (VALU + stores) runs
-//     beside the other half's MFMA stream instead of both idling the matrix pipe together (conv2_1 has ONE chunk per tile).
+//   * one workgroup barrier per sub-chunk (3 steps); the loop body is one 64-channel chunk = two sub-chunks.
 // Pixel lanes are laid out along rows in BOTH modes (lanes {0-3,12-15} = even columns, {4-11} = odd columns), which is
 // conflict-free for 64-byte pixels under the chunk ^ ((px >> 2) & 3) swizzle; the fused MaxPool2d(2,2) is a plain max
 // of two accumulator rows plus one masked row-rotate per side.
@@ -193,22 +190,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         __builtin_amdgcn_s_barrier();                                                                          \
         issue_next_patch();                                                                                    \
     }
-    // HANDOFF: wave-uniform -- the late half (waves 4-7) takes the hand-off after steps 0 and 3
-#define G3_STEP_H(T, HANDOFF)                                                                                  \
+#define G3_STEP(T)                                                                                             \
     {                                                                                                          \
         G3_LOAD_A((T) + 1, sb_cur)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         G3_ROWS_0_15(T)                                                                                        \
-        if (HANDOFF) G3_HANDOFF()                                                                              \
         G3_SET_E((T) + 1, bufb)                                                                                \
         G3_READ((T) + 1, 0) G3_ROW(T, 16)                                                                      \
         G3_READ((T) + 1, 1) G3_ROW(T, 17)                                                                      \
     }
-#define G3_STEP(T) G3_STEP_H(T, false)
-    // last step of a sub-chunk (T = 2 or 5): the early half takes the hand-off here; every wave moves on to the next
-    // sub-chunk's buffer (the late half saw its pieces landed at its own hand-off, two steps ago).  After the last
-    // sub-chunk the barrier, the reads and the weight loads still run, on valid but unused data, so that the loop body has
-    // one shape.
+    // last step of a sub-chunk (T = 2 or 5) with the hand-off.  After the last sub-chunk the barrier, the reads and the
+    // weight loads still run, on valid but unused data, so that the loop body has one shape.
 #define G3_STEP_HANDOFF(T, TN, SBN)                                                                            \
     {                                                                                                          \
         G3_LOAD_A(TN, SBN)                                                                                     \
@@ -216,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         G3_ROWS_0_15(T)                                                                                        \
         const int nbufi = (bufi == 2) ? 0 : bufi + 1;                                                          \
         const unsigned nbufb = lds_a + (unsigned)nbufi * G3_A_BYTES;                                           \
-        if (!late) G3_HANDOFF()                                                                                \
+        G3_HANDOFF()                                                                                           \
         G3_SET_E(TN, nbufb)                                                                                    \
         G3_READ(TN, 0) G3_ROW(T, 16)                                                                           \
         G3_READ(TN, 1) G3_ROW(T, 17)                                                                           \
@@ -248,12 +240,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     G3_READ(0, 1)
 
     const int lp = lane & 15;
-    const bool late = wid >= 4;                          // the second-dispatched half: SIMD partners of waves 0-3
     for (int cc = 0; cc < total_chunks; ++cc) {
         asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
-        G3_STEP_H(0, late) G3_STEP(1)
+        G3_STEP(0) G3_STEP(1)
         G3_STEP_HANDOFF(2, 3, sb_cur)
-        G3_STEP_H(3, late) G3_STEP(4)
+        G3_STEP(3) G3_STEP(4)
         G3_STEP_HANDOFF(5, 0, sb_next)
         sb_cur = sb_next;
 
@@ -332,7 +323,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
 #undef G3_STEP_HANDOFF
 #undef G3_STEP
-#undef G3_STEP_H
 #undef G3_HANDOFF
 #undef G3_ROWS_0_15
 #undef G3_RP
