@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 #include <math.h>
+#include <type_traits>
 
 #define MT_TG 128
 #define MT_TQ 128
@@ -88,25 +89,32 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
     const unsigned char* gbase = (const unsigned char*)a.g;
     const unsigned char* qbase = (const unsigned char*)a.q;
     const size_t rowbytes = (size_t)a.D * ES;
+    const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (unsigned)((size_t)a.Gn * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (unsigned)((size_t)a.Qn * rowbytes), 0x00020000);
 
-    u32x4 greg[PASS], qreg[PASS];
-    auto load_tile = [&](int kt) {
+    // register staging, TWO K-steps deep: the loads of step kt + 2 are issued before the MFMAs of step kt, so a load has a
+    // whole iteration (and the barrier) to land before it is written to LDS -- one step deep, every iteration waited out most
+    // of an L2 / HBM round trip (~2 us per K-step, the whole kernel was that latency times D / 64)
+    constexpr int NS = F32 ? 1 : 2;      // staging depth (the f32 rows are twice as wide: two sets would spill)
+    u32x4 greg[NS][PASS], qreg[NS][PASS];
+    auto load_tile = [&](int kt, int slot) {
 #pragma unroll
         for (int i = 0; i < PASS; ++i) {
             int gr = tile_g * MT_TG + r0 + i * RPP;
             int qr = tile_q * MT_TQ + r0 + i * RPP;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            greg[i] = (gr < a.Gn) ? *reinterpret_cast<const u32x4*>(gbase + (size_t)gr * rowbytes + (size_t)kt * ROWB + c * 16) : z;
-            qreg[i] = (qr < a.Qn) ? *reinterpret_cast<const u32x4*>(qbase + (size_t)qr * rowbytes + (size_t)kt * ROWB + c * 16) : z;
+            // buffer loads: rows past the end are out of the descriptor's range and read as zeros -- no branch around the load,
+            // so the compiler can count the loads in flight (behind a branch it waits with vmcnt(0): the staging collapses)
+            greg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, (unsigned)gr * (unsigned)rowbytes + (unsigned)(kt * ROWB + c * 16), 0, 0);
+            qreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_q, (unsigned)qr * (unsigned)rowbytes + (unsigned)(kt * ROWB + c * 16), 0, 0);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int slot) {
 #pragma unroll
         for (int i = 0; i < PASS; ++i) {
             int row = r0 + i * RPP;
             int phys = c ^ ((row / RPB) & (CPR - 1));
-            *reinterpret_cast<u32x4*>(Gs + (size_t)buf * MT_TG * ROWB + row * ROWB + phys * 16) = greg[i];
-            *reinterpret_cast<u32x4*>(Qs + (size_t)buf * MT_TQ * ROWB + row * ROWB + phys * 16) = qreg[i];
+            *reinterpret_cast<u32x4*>(Gs + (size_t)buf * MT_TG * ROWB + row * ROWB + phys * 16) = greg[slot][i];
+            *reinterpret_cast<u32x4*>(Qs + (size_t)buf * MT_TQ * ROWB + row * ROWB + phys * 16) = qreg[slot][i];
         }
     };
 
@@ -120,13 +128,21 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
 
     const int nk = a.D / MT_BK;
     const int lr = lane & 31, lh = lane >> 5;
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, 0);
+    if (NS == 2) load_tile(nk > 1 ? 1 : 0, 1);
+    store_tile(0, 0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);
+    // (the loop is unrolled by two so that the staging slot of a step is a compile-time index: registers, not scratch)
+    auto k_step = [&](int kt, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value % NS;  // slot holding step kt + 1; the loads of step kt + 2 go to the other one
+        // No branch around the loads or the LDS stores (past the last K-step they re-fetch the last tile into buffers nobody
+        // reads): with one straight-line path the compiler's vmcnt bookkeeping is exact -- behind `if (kt + 2 < nk)` it waited
+        // for the minimum over both paths, i.e. for the newest loads as well.
+        const int last = nk - 1;
+        if (NS == 2) load_tile(kt + 2 < nk ? kt + 2 : last, (SLOT + 1) % NS);
+        else load_tile(kt + 1 < nk ? kt + 1 : last, 0);
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the MFMA section (the scheduler otherwise sinks them to the barrier)
         const unsigned char* Gb = Gs + (size_t)cur * MT_TG * ROWB;
         const unsigned char* Qb = Qs + (size_t)cur * MT_TQ * ROWB;
         if constexpr (!F32) {
@@ -171,15 +187,27 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][e], bfr[nt][e], acc[mt][nt], 0, 0, 0);
             }
         }
-        if (more) store_tile(cur ^ 1);
+        store_tile(cur ^ 1, SLOT);
         __syncthreads();
         cur ^= 1;
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_step(kt, std::integral_constant<int, 1>{});
+        k_step(kt + 1, std::integral_constant<int, 0>{});
     }
+    if (kt < nk) k_step(kt, std::integral_constant<int, 1>{});     // odd number of K-steps
 
     // ---- epilogue: distances -> LDS [g][q], then per-query top-k -------------
     float* Tl = reinterpret_cast<float*>(smem);                       // 128 x 128 f32 = 64 KiB
     float* cd = reinterpret_cast<float*>(smem + MT_TG * MT_TQ * 4);   // [2][128]
     int* cix = reinterpret_cast<int*>(smem + MT_TG * MT_TQ * 4 + 2 * 128 * 4);
+    float* s_gn = reinterpret_cast<float*>(smem + MT_TG * MT_TQ * 4 + 4 * 128 * 4);   // the tile's 128 gallery norms (one coalesced load
+    if (tid < MT_TG) {                                                                 // instead of 64 scattered ones per lane)
+        const int gg = tile_g * MT_TG + tid;
+        s_gn[tid] = (gg < a.Gn) ? a.gn[gg] : 1.f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int ql = wp * 64 + nt * 32 + lr;
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
                 const int gg = tile_g * MT_TG + gl;
                 float d = INFINITY;
                 if (gg < a.Gn) {
-                    d = 1.f - acc[mt][nt][r] / (qn * a.gn[gg]);
+                    d = 1.f - acc[mt][nt][r] / (qn * s_gn[gl]);
                     if (!(d == d)) d = INFINITY;   // a NaN distance (non-finite embedding) sorts last and still yields a valid index
                 }
                 Tl[gl * MT_TQ + ql] = d;
@@ -207,10 +235,15 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
     for (int r = 0; r < a.k; ++r) {
         float bd = INFINITY;
         int bi = 0x7FFFFFFF;
-        for (int g = half * 64; g < half * 64 + 64; ++g) {
-            const float d = Tl[g * MT_TQ + ql];
-            const int gi = tile_g * MT_TG + g;
-            if (lex_lt(pd, pi, d, gi) && lex_lt(d, gi, bd, bi)) { bd = d; bi = gi; }
+        for (int g0 = half * 64; g0 < half * 64 + 64; g0 += 8) {
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[u] = Tl[(g0 + u) * MT_TQ + ql];          // 8 LDS reads in flight
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int gi = tile_g * MT_TG + g0 + u;
+                if (lex_lt(pd, pi, dv[u], gi) && lex_lt(dv[u], gi, bd, bi)) { bd = dv[u]; bi = gi; }
+            }
         }
         cd[half * 128 + ql] = bd;
         cix[half * 128 + ql] = bi;
@@ -228,24 +261,47 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
     }
 }
 
-__global__ void match_merge_kernel(const float* __restrict__ part_d, const int* __restrict__ part_i, int Qn, int n,
-                                   int k, long long* __restrict__ out_idx, float* __restrict__ out_dist) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per query: the n partial (distance, index) pairs are spread over the lanes (coalesced loads, all in flight at once --
+// one thread walking them paid an L2 round trip per entry), each of the k rounds takes the wave-wide lexicographic minimum of
+// the entries greater than the previous pick.
+__global__ __launch_bounds__(256) void match_merge_kernel(const float* __restrict__ part_d, const int* __restrict__ part_i, int Qn, int n,
+                                                          int k, long long* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= Qn) return;
     const float* d = part_d + (size_t)q * n;
     const int* ix = part_i + (size_t)q * n;
+    constexpr int PER = 8;                      // entries per lane held in registers: n <= 512, else the strided loop below
+    float dv[PER];
+    int iv[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int j = e * 64 + lane;
+        dv[e] = (j < n) ? d[j] : INFINITY;
+        iv[e] = (j < n) ? ix[j] : 0x7FFFFFFF;
+    }
     float pd = -INFINITY;
     int pi = -1;
     for (int r = 0; r < k; ++r) {
         float bd = INFINITY;
         int bi = 0x7FFFFFFF;
-        for (int j = 0; j < n; ++j) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            if (lex_lt(pd, pi, dv[e], iv[e]) && lex_lt(dv[e], iv[e], bd, bi)) { bd = dv[e]; bi = iv[e]; }
+        for (int j = PER * 64 + lane; j < n; j += 64) {            // (n > 512: the tail straight from memory)
             const float dj = d[j];
             const int ij = ix[j];
             if (lex_lt(pd, pi, dj, ij) && lex_lt(dj, ij, bd, bi)) { bd = dj; bi = ij; }
         }
-        out_idx[(size_t)q * k + r] = (long long)bi;
-        if (out_dist) out_dist[(size_t)q * k + r] = bd;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const int oi = __shfl_xor(bi, off);
+            if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+        }
+        if (lane == 0) {
+            out_idx[(size_t)q * k + r] = (long long)bi;
+            if (out_dist) out_dist[(size_t)q * k + r] = bd;
+        }
         pd = bd; pi = bi;
     }
 }
@@ -262,6 +318,10 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
     if (D <= 0 || D % MT_BK != 0 || k < 1 || k > MATCH_KMAX || Gn < k) return CVPCE_ERR_ARG;
     if (Qn <= 0) return CVPCE_OK;
     if (workspace_bytes < cvpce_match_workspace_bytes(Qn, Gn, k)) return CVPCE_ERR_ARG;
+    {   // 32-bit buffer offsets (rows rounded up to whole tiles stay below 2^32)
+        const unsigned long long es = is_f32 ? 4 : 2;
+        if (((unsigned long long)Gn + MT_TG) * D * es >= (1ull << 32) || ((unsigned long long)Qn + MT_TQ) * D * es >= (1ull << 32)) return CVPCE_ERR_ARG;
+    }
     MatchArgs a;
     a.q = queries; a.g = gallery; a.qn = q_norms; a.gn = g_norms; a.Qn = Qn; a.Gn = Gn; a.D = D; a.k = k;
     a.tiles_g = (Gn + MT_TG - 1) / MT_TG;
@@ -274,7 +334,7 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)match_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 256) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)match_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4 + 2048) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)match_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4 + 2048 + 512) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
@@ -282,10 +342,10 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
         size_t smem = (size_t)2 * 2 * 128 * 256;    // 128 KiB staging (>= 66 KiB epilogue image)
         hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), smem, s, a);
     } else {
-        size_t smem = (size_t)128 * 128 * 4 + 2048;  // epilogue image dominates (staging needs 64 KiB)
+        size_t smem = (size_t)128 * 128 * 4 + 2048 + 512;  // epilogue image (+ candidates, + the tile's gallery norms) dominates (staging needs 64 KiB)
         hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), smem, s, a);
     }
-    hipLaunchKernelGGL(match_merge_kernel, dim3((Qn + 63) / 64), dim3(64), 0, s, a.part_d, a.part_i, Qn, a.tiles_g * k,
+    hipLaunchKernelGGL(match_merge_kernel, dim3((Qn + 3) / 4), dim3(256), 0, s, a.part_d, a.part_i, Qn, a.tiles_g * k,
                        k, out_idx, out_dist);
     return cvpce_check_launch();
 }

@@ -101,13 +101,13 @@ def emulated_detect(img, sd, dpi):
 
 @torch.no_grad()
 def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
-        k=5, images_per_batch=8, seed=0, control_images=0, log=None):
+        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None):
     from cvpce_amd import ops, production, synthetic, datautils
     from oracle import gln as og, crop as ocrop, match as omatch
     log = log or (lambda *a: None)
     dev = torch.device('cuda:0')
     t_start = time.perf_counter()
-    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain)
     enc = synthetic.synthetic_macvgg(seed=1)
     det_sd = {k_: v.clone() for k_, v in det.state_dict().items()}
     enc_sd = {k_: v.clone() for k_, v in enc.state_dict().items()}
@@ -122,6 +122,7 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
     orc_gal = oracle_embed(gal_tanh, enc_sd, oracle_device)
     log(f'[accuracy] oracle gallery embedded on {oracle_device} ({time.perf_counter() - t:.1f} s)')
     report = {'n_images': n_images, 'image_size': image_size, 'detections_per_img': dpi, 'oracle_device_embedder': oracle_device,
+              'detector_residual_gain': residual_gain,
               'data': 'structured shelves (cvpce_amd.synthetic.structured_shelf), seeded random-init weights'}
     if oracle_device != 'cpu':                                           # the GPU run of the oracle code vs its CPU run
         chk = oracle_embed(gal_tanh[:8], enc_sd, 'cpu')
@@ -284,11 +285,12 @@ def main():
     ap.add_argument('--detections-per-img', type=int, default=200)
     ap.add_argument('--oracle-device', default='cpu', choices=['cpu', 'cuda'])
     ap.add_argument('--control-images', type=int, default=8, help='images of the bf16-emulation control (oracle/bf16_model.py)')
+    ap.add_argument('--residual-gain', type=float, default=1.0, help='synthetic_gln residual_gain (conditioning of the random detector)')
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     rep = run(a.images, a.image_size, tuple(int(g) for g in a.galleries.split(',')), a.detections_per_img, a.queries, a.oracle_device,
-              control_images=a.control_images, log=lambda *x: print(*x, flush=True))
+              control_images=a.control_images, residual_gain=a.residual_gain, log=lambda *x: print(*x, flush=True))
     text = json.dumps(rep, indent=1)
     print(text)
     if a.out:
