@@ -5,7 +5,7 @@ reference for
     cvpce gln eval | gln detect | dihe eval | dihe prebuild-index | eval-product-detection | eval-planograms
 
 Training, hyper-parameter search, dataset visualisation and plotting commands are out of scope.  Options that only steer
-the reference's DataLoader / multiprocessing / matplotlib (`--dataloader-workers`, `--metric-workers`, `--plots`,
+the reference's DataLoader / matplotlib (`--dataloader-workers`, `--plots`,
 `--plot-res-reduction`) are accepted and ignored: images are read in-process and every metric is printed.
 
     python -m cvpce_amd.cli --help
@@ -57,7 +57,7 @@ def gln():
               help='Path to annotations used for testing')
 @click.option('--batch-size', type=int, default=1, show_default=True, help='Batch size')
 @click.option('--dataloader-workers', type=int, default=4, show_default=True, help='(ignored) Number of data loading processes')
-@click.option('--metric-workers', type=int, default=8, show_default=True, help='(ignored) Number of metric calculating processes')
+@click.option('--metric-workers', type=int, default=8, show_default=True, help='Number of metric calculating processes (0 = in-process)')
 @click.option('--iou-threshold', '-t', type=float, multiple=True, default=(0.5,), show_default=True,
               help='IoU thresholds to calculate metrics for')
 @click.option('--coco/--no-coco', default=False, show_default=True,
@@ -80,7 +80,7 @@ def eval(dataset, imgs, annotations, batch_size, dataloader_workers, metric_work
         data = datautils.GPBaselineDataset(imgs, annotations)
     thresholds = _coco_or(iou_threshold, coco)
     evaluation = proposals_eval.evaluate_gln(state_file, data, thresholds=thresholds, batch_size=batch_size,
-                                             trim_module_prefix=trim_module_prefix)
+                                             num_metric_processes=metric_workers, trim_module_prefix=trim_module_prefix)
     ap = ar = 0
     for t in thresholds:
         print(f'{t}:\t{evaluation[t]}')

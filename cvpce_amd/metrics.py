@@ -119,3 +119,93 @@ def calculate_metrics(targets, predictions, confidences, iou_thresholds=(0.5,)):
             for key in per_thr[t]:
                 per_thr[t][key].append(m[t][key])
     return _do_calculate(iou_thresholds, per_thr, confs, total)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Multiprocess variant (cvpce/metrics.py:140-175): per-image matching in worker processes while the GPU keeps detecting.
+# Same protocol as the reference -- a JoinableQueue of (targets, predictions, confidences) triples, one `None` per worker
+# to stop them, an output queue drained by one collector that sends the result dictionary through a pipe -- so
+# proposals_eval.evaluate_gln_async reads like the reference's.  Workers are SPAWNED (not forked): the parent has the GPU
+# open, the children import only this host-only module.  The collector re-orders results by image number before merging,
+# so the result is identical to calculate_metrics (the reference merges in completion order, which only permutes ties).
+# ---------------------------------------------------------------------------------------------------------------------
+def _image_processer(input_queue, output_queue, iou_thresholds):
+    torch.set_num_threads(1)
+    for seq, target, prediction, confidence in iter(input_queue.get, None):
+        m, c, n = _process_one(torch.from_numpy(target), torch.from_numpy(prediction), torch.from_numpy(confidence), iou_thresholds)
+        # results cross the process boundary BY VALUE (numpy): torch tensors would be shared through file descriptors served
+        # by the producing process, which may have exited before the collector reads them
+        m = {t: {'true_positives': d['true_positives'].numpy(), 'false_positives': d['false_positives'].numpy(),
+                 'recall_300': float(d['recall_300'])} for t, d in m.items()}
+        output_queue.put((seq, m, c.numpy(), n))
+        input_queue.task_done()
+    input_queue.task_done()
+
+
+def _metric_calculator(output_queue, pipe, iou_thresholds):
+    results = []
+    for item in iter(output_queue.get, None):
+        results.append(item)
+        output_queue.task_done()
+    results.sort(key=lambda r: r[0])
+    per_thr = {t: {'true_positives': [], 'false_positives': [], 'recall_300': []} for t in iou_thresholds}
+    confs, total = [], 0
+    for _, m, c, n in results:
+        confs.append(torch.from_numpy(c))
+        total += n
+        for t in iou_thresholds:
+            per_thr[t]['true_positives'].append(torch.from_numpy(m[t]['true_positives']))
+            per_thr[t]['false_positives'].append(torch.from_numpy(m[t]['false_positives']))
+            per_thr[t]['recall_300'].append(torch.tensor(m[t]['recall_300']) if len(m[t]['true_positives']) else 0)
+    res = _do_calculate(iou_thresholds, per_thr, confs, total) if results else None
+    if res is not None:       # the result dictionary goes through the pipe by value as well
+        res = {t: {k: ({kk: vv.numpy() for kk, vv in v.items()} if k == 'raw' else (v.item() if torch.is_tensor(v) else v))
+                   for k, v in d.items()} for t, d in res.items()}
+    pipe.send(res)
+    output_queue.task_done()
+
+
+def _result_from_pipe(res):
+    if res is None:
+        return None
+    return {t: {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if k == 'raw' else torch.tensor(v)) for k, v in d.items()}
+            for t, d in res.items()}
+
+
+class _ResultPipe:
+    def __init__(self, conn):
+        self._c = conn
+
+    def recv(self):
+        return _result_from_pipe(self._c.recv())
+
+
+class _SequencedQueue:
+    """The reference's `queue.put((targets, predictions, confidences))` interface over a JoinableQueue whose items also
+    carry the image's sequence number."""
+
+    def __init__(self, queue):
+        self._q, self._n = queue, 0
+
+    def put(self, item):
+        if item is None:
+            self._q.put(None)
+        else:
+            self._q.put((self._n,) + tuple(t.detach().cpu().contiguous().numpy() for t in item))
+            self._n += 1
+
+    def join(self):
+        self._q.join()
+
+
+def calculate_metrics_async(processes=4, iou_thresholds=(0.5,)):
+    """-> (input queue, output queue, result pipe), used exactly like the reference's (cvpce/metrics.py:163-175)."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    iou_thresholds = tuple(iou_thresholds)
+    input_queue, output_queue = ctx.JoinableQueue(), ctx.JoinableQueue()
+    out_pipe, in_pipe = ctx.Pipe()
+    for _ in range(processes):
+        ctx.Process(target=_image_processer, args=(input_queue, output_queue, iou_thresholds), daemon=True).start()
+    ctx.Process(target=_metric_calculator, args=(output_queue, in_pipe, iou_thresholds), daemon=True).start()
+    return _SequencedQueue(input_queue), output_queue, _ResultPipe(out_pipe)

@@ -49,7 +49,7 @@ class Classifier:
     def __init__(self, encoder, sample_set, device=torch.device('cuda'), emb_device=torch.device('cuda'),
                  batch_size=32, num_workers=8, k=1, load=None, verbose=False, match_dtype=torch.float32):
         self.batch_size = batch_size
-        self.num_workers = num_workers  # kept for signature parity; gallery tensors are batched in-process
+        self.num_workers = num_workers  # reader threads of build_index (the reference's DataLoader workers)
         self.device = device
         self.emb_device = emb_device
         self.k = k
@@ -81,18 +81,39 @@ class Classifier:
         self.embedding, self.annotations = embedding, annotations
         self._refresh_gallery()
 
+    def _gallery_items(self, sample_set):
+        """sample_set[0], sample_set[1], ... in order, read by `num_workers` threads a bounded window ahead -- the counterpart of
+        the reference's DataLoader(num_workers=..., pin_memory=True) (production.py:37-39): decoding and resizing a product
+        photo (PIL releases the GIL) would otherwise serialise with the GPU, which embeds > 5 000 gallery images/s."""
+        n = len(sample_set)
+        if self.num_workers <= 0 or n < 2:
+            for i in range(n):
+                yield sample_set[i]
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        window = max(2 * self.num_workers, self.batch_size)
+        with ThreadPoolExecutor(self.num_workers) as pool:
+            pending, nxt = deque(), 0
+            while nxt < n or pending:
+                while nxt < n and len(pending) < window:
+                    pending.append(pool.submit(sample_set.__getitem__, nxt))
+                    nxt += 1
+                yield pending.popleft().result()
+
     def build_index(self, sample_set, verbose=False):
         """production.py:36-48.  Gallery images are already in [-1,1] (datautils.py:446): no scale_to_tanh."""
         chunks, annotations, imgs = [], [], []
+        pin = torch.cuda.is_available()
 
         def flush():
             if imgs:
-                batch = torch.stack(imgs).to(device=self.device)
+                batch = torch.stack(imgs)
+                batch = (batch.pin_memory() if pin and not batch.is_cuda else batch).to(device=self.device, non_blocking=True)
                 chunks.append(self.encoder(batch).detach().to(device=self.emb_device))
                 imgs.clear()
 
-        for i in range(len(sample_set)):
-            item = sample_set[i]
+        for i, item in enumerate(self._gallery_items(sample_set)):
             imgs.append(item[0])
             annotations.append(item[-1])
             if len(imgs) == self.batch_size:

@@ -169,3 +169,26 @@ def test_utils_and_reference_api_names():
             assert hasattr(mod, n), (mod.__name__, n)
     d = classification.distance(torch.tensor([[1.0, 0.0]]), torch.tensor([[0.0, 1.0]]))
     assert torch.allclose(d, torch.tensor([1.0]))
+
+
+def test_gallery_reader_pool_keeps_order():
+    """Classifier.build_index reads the gallery through `num_workers` threads (the reference's DataLoader workers,
+    production.py:37-39): items come back in index order whatever the per-item latency."""
+    import time
+    from cvpce_amd import production
+
+    class Slow:
+        def __len__(self):
+            return 37
+
+        def __getitem__(self, i):
+            time.sleep(0.001 * (i % 5))
+            return torch.full((3, 4, 4), float(i)), f'a{i}'
+
+    c = production.Classifier.__new__(production.Classifier)
+    c.batch_size = 8
+    for workers in (4, 0):
+        c.num_workers = workers
+        items = list(c._gallery_items(Slow()))
+        assert [a for _, a in items] == [f'a{i}' for i in range(37)]
+        assert all(float(t[0, 0, 0]) == i for i, (t, _) in enumerate(items))
