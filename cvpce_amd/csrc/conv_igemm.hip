@@ -882,21 +882,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     const bf16_t* wrow = a.wgt + (size_t)(tile_c * TC + r0) * a.K_pad + c * 8;
 
-    u32x4 wreg[WPASS], preg[PPASS];
+    // Register staging, TWO K-steps deep, and no branch anywhere around a load: the gather goes through a buffer descriptor
+    // over the input tensor, a tap outside the image (zero padding), a ragged row or a K-step past the end gets an offset
+    // outside the descriptor's range and reads as zeros.  Behind `if (ok)` branches the compiler cannot count the loads
+    // in flight and waits with vmcnt(0) before the next ones are issued: every K-step then costs a full L2 round trip
+    // (the same repair as in csrc/match.hip; these small-M layers are pure latency).
+    const __amdgpu_buffer_rsrc_t srd_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    u32x4 wreg[2][WPASS], preg[2][PPASS];
+    const int nk = a.K_pad / BK;
 
-#define CVPCE_LOAD_TILE(KT)                                                                                    \
+#define CVPCE_LOAD_TILE(KT, SLOT)                                                                              \
     {                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < WPASS; ++i) wreg[i] =                                            \
-            *reinterpret_cast<const u32x4*>(wrow + (size_t)i * RPP * a.K_pad + (KT) * BK);                     \
+        const int ktw_ = (KT) < nk ? (KT) : nk - 1;      /* past the end: re-read the last weight K-step */      \
+        _Pragma("unroll") for (int i = 0; i < WPASS; ++i) wreg[SLOT][i] =                                      \
+            *reinterpret_cast<const u32x4*>(wrow + (size_t)i * RPP * a.K_pad + ktw_ * BK);                     \
         const bool tap_ok = (BK == 64) ? (ci < a.Cin) : (kh < a.KH);                                           \
         _Pragma("unroll") for (int i = 0; i < PPASS; ++i) {                                                    \
             const int iy = piy[i] + kh, ix = pix[i] + kw;                                                      \
             const bool ok = tap_ok && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;              \
-            const size_t off =                                                                                 \
-                (size_t)(pbase[i] + (iy >> a.in_up_shift) * a.W + (ix >> a.in_up_shift)) * a.Cin + ci;         \
-            u32x4 v = {0u, 0u, 0u, 0u};                                                                        \
-            if (ok) v = *reinterpret_cast<const u32x4*>(a.in + off);                                           \
-            preg[i] = v;                                                                                       \
+            const unsigned off =                                                                               \
+                ((unsigned)(pbase[i] + (iy >> a.in_up_shift) * a.W + (ix >> a.in_up_shift)) * (unsigned)a.Cin + (unsigned)ci) * 2u; \
+            preg[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_in, ok ? off : 0xFFFFFFF0u, 0, 0);      \
         }                                                                                                      \
         if (BK == 64) { /* chunk-major K order (Cin % 64 == 0), see conv_dma_kernel */                         \
             if (++kw == a.KW) {                                                                                \
@@ -911,17 +917,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             }                                                                                                  \
         }                                                                                                      \
     }
-#define CVPCE_STORE_TILE(BUF)                                                                                  \
+#define CVPCE_STORE_TILE(BUF, SLOT)                                                                            \
     {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < WPASS; ++i) {                                                    \
             const int row = r0 + i * RPP;                                                                      \
             const int phys = c ^ ((row / RPB) & (CPR - 1));                                                    \
-            *reinterpret_cast<u32x4*>(Ws + (BUF) * TC * BK + row * BK + phys * 8) = wreg[i];                   \
+            *reinterpret_cast<u32x4*>(Ws + (BUF) * TC * BK + row * BK + phys * 8) = wreg[SLOT][i];             \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < PPASS; ++i) {                                                    \
             const int row = r0 + i * RPP;                                                                      \
             const int phys = c ^ ((row / RPB) & (CPR - 1));                                                    \
-            *reinterpret_cast<u32x4*>(Ps + (BUF) * TP * BK + row * BK + phys * 8) = preg[i];                   \
+            *reinterpret_cast<u32x4*>(Ps + (BUF) * TP * BK + row * BK + phys * 8) = preg[SLOT][i];             \
         }                                                                                                      \
     }
 
@@ -933,19 +939,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = a.K_pad / BK;
-    CVPCE_LOAD_TILE(0)
-    CVPCE_STORE_TILE(0)
+    CVPCE_LOAD_TILE(0, 0)
+    CVPCE_LOAD_TILE(1, 1)
+    CVPCE_STORE_TILE(0, 0)
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) CVPCE_LOAD_TILE(kt + 1)
-        mfma_kstep<MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc);
-        if (more) CVPCE_STORE_TILE(cur ^ 1)
-        __syncthreads();
-        cur ^= 1;
+    // One straight-line step: issue the loads of step kt + 2 into the slot step kt's data just left, run the MFMAs of step kt
+    // from LDS, write step kt + 1 (loaded one step ago) to the other LDS buffer.  Unrolled by two so that the register
+    // slots are compile-time indices; past the last K-step the loads fetch zeros / the last weight step into buffers
+    // nobody reads.
+#define CVPCE_KSTEP(KT, SLOT)                                                                                  \
+    {                                                                                                          \
+        CVPCE_LOAD_TILE((KT) + 2, (SLOT) ^ 1)                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        mfma_kstep<MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc); \
+        CVPCE_STORE_TILE(cur ^ 1, SLOT)                                                                        \
+        __syncthreads();                                                                                       \
+        cur ^= 1;                                                                                              \
     }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        CVPCE_KSTEP(kt, 1)
+        CVPCE_KSTEP(kt + 1, 0)
+    }
+    if (kt < nk) CVPCE_KSTEP(kt, 1)
+#undef CVPCE_KSTEP
 #undef CVPCE_LOAD_TILE
 #undef CVPCE_STORE_TILE
     conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
