@@ -438,7 +438,7 @@ def run_match_stress(args, rank, local_rank, world, dev):
         # otherwise be what the events time
         per_graph = 20
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             for _ in range(per_graph):
                 ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
         graph.replay()

@@ -482,7 +482,8 @@ class GLNEngine:
             self.transform(images, out=static_in)
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread-local capture mode: other threads -- e.g. an RCCL watchdog polling its events -- may keep issuing HIP calls)
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 static_out = self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
             entry.update(graph=g, static_in=static_in, static_out=static_out)
         else:

@@ -24,10 +24,10 @@ def _free_port():
     return port
 
 
-def _bench(world, images_per_gpu):
+def _bench(world, images_per_gpu, self_launch=False):
     env = dict(os.environ, CVPCE_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     tail = [os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--images-per-gpu', str(images_per_gpu)] + COMMON
-    if world == 1:
+    if world == 1 or self_launch:        # self_launch: `python bench.py --gpus N` starts torch.distributed.run as a child process
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
@@ -49,3 +49,10 @@ def test_bench_two_ranks_bit_identical_to_one_rank(cuda):
     assert two['verify']['per_image'] == one['verify']['per_image']      # every image: same boxes, scores, labels, matched indices
     assert two['verify']['digest'] == one['verify']['digest']
     assert len(set(one['verify']['per_image'].values())) == 4            # (different images do give different results)
+
+
+def test_bench_gpus_flag_starts_the_launcher_itself(cuda):
+    """`python bench.py --gpus 2` outside torch.distributed.run must not report a 1-rank number as a 2-GPU run (round-1 advisor
+    finding): it starts the launcher as a child process and relays rank 0's line."""
+    two = _bench(2, 1, self_launch=True)
+    assert two['n_gpus'] == 2 and two['config']['global_images'] == 2 and two['verify']['images'] == 2
