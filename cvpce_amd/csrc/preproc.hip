@@ -123,6 +123,76 @@ __global__ void crop_resize_kernel(const float* __restrict__ img, const float* _
     }
 }
 
+// Modes 1 / 2 for the embedder, TWO output pixels per thread: 24 independent gathers in flight per thread instead of 12 (the
+// one-pixel kernel is bound by load latency, not bandwidth) and one 16-byte store per thread in mode 2.  Same arithmetic,
+// expression for expression, as crop_resize_kernel.
+template <int MODE>
+__global__ void crop_resize2_kernel(const float* __restrict__ img, const float* __restrict__ boxes, const int* __restrict__ count,
+                                    bf16_t* __restrict__ out, int H0, int W0, int S, float m0, float m1, float m2, float s0,
+                                    float s1, float s2) {
+    const int p = blockIdx.z;
+    if (count && p >= *count) return;
+    const int oy = blockIdx.y;
+    const int ox0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (ox0 >= S) return;
+    const float* b = boxes + (size_t)p * 4;
+    long long x1 = (long long)b[0], y1 = (long long)b[1], x2 = (long long)b[2], y2 = (long long)b[3];
+    x1 = x1 < 0 ? 0 : (x1 > W0 ? W0 : x1);
+    x2 = x2 < 0 ? 0 : (x2 > W0 ? W0 : x2);
+    y1 = y1 < 0 ? 0 : (y1 > H0 ? H0 : y1);
+    y2 = y2 < 0 ? 0 : (y2 > H0 ? H0 : y2);
+    int cw = (int)(x2 - x1), ch = (int)(y2 - y1);
+    if (cw < 0) cw = 0;
+    if (ch < 0) ch = 0;
+    const int larger = cw > ch ? cw : ch;
+    float v[2][3] = {{0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}};
+    if (larger > 0) {
+        const float sc = (float)larger / (float)S;
+        int yy0, yy1, xx0[2], xx1[2];
+        float ly0, ly1, lx0[2], lx1[2];
+        src_index(sc, oy, larger, yy0, yy1, ly0, ly1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) src_index(sc, ox0 + u, larger, xx0[u], xx1[u], lx0[u], lx1[u]);
+        float t[2][3][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pl = img + (size_t)c * H0 * W0;
+                auto at = [&](int yy, int xx) -> float {
+                    return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
+                };
+                t[u][c][0] = at(yy0, xx0[u]); t[u][c][1] = at(yy0, xx1[u]); t[u][c][2] = at(yy1, xx0[u]); t[u][c][3] = at(yy1, xx1[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[u][c] = ly0 * (lx0[u] * t[u][c][0] + lx1[u] * t[u][c][1]) + ly1 * (lx0[u] * t[u][c][2] + lx1[u] * t[u][c][3]);
+    }
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    bf16_t o[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[u][c] = f32_to_bf16((v[u][c] * 2.f - 1.f - mean[c]) / stdv[c]);
+        o[u][3] = (bf16_t)0.f;
+    }
+    const size_t pix = ((size_t)p * S + oy) * S + ox0;
+    if (MODE == 2) {
+        const bf16x8 w = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+        if (ox0 + 1 < S) *reinterpret_cast<bf16x8*>(out + pix * 4) = w;
+        else *reinterpret_cast<bf16x4*>(out + pix * 4) = bf16x4{o[0][0], o[0][1], o[0][2], o[0][3]};
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (ox0 + u < S) {
+                const bf16x8 w = {o[u][0], o[u][1], o[u][2], (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                *reinterpret_cast<bf16x8*>(out + (pix + u) * 8) = w;
+            }
+    }
+}
+
 extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
                                  int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream) {
     if (!img || !boxes || !out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
@@ -132,6 +202,16 @@ extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int
     dim3 grid((S + 127) / 128, S, max_boxes);
     float m[3] = {0, 0, 0}, s[3] = {1, 1, 1};
     if (mode != 0) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; s[i] = std3[i]; }
+    if (mode != 0 && S % 2 == 0) {
+        dim3 grid2((S / 2 + 127) / 128, S, max_boxes);
+        if (mode == 2)
+            hipLaunchKernelGGL(crop_resize2_kernel<2>, grid2, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
+                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2]);
+        else
+            hipLaunchKernelGGL(crop_resize2_kernel<1>, grid2, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
+                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2]);
+        return cvpce_check_launch();
+    }
     hipLaunchKernelGGL(crop_resize_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, out, H0, W0,
                        S, mode, m[0], m[1], m[2], s[0], s[1], s[2]);
     return cvpce_check_launch();

@@ -229,8 +229,9 @@ class BatchedPipeline:
         self.classifier = classifier
         self.confidence_threshold = confidence_threshold
 
-    def _crop_embed_match(self, images, det_out, counts, embed_batch=None):
-        """Stages after the detector, on the current stream: RoI crops -> embeddings -> matched indices."""
+    def _crops(self, images, det_out):
+        """RoI crops of every image's confident boxes, launched WITHOUT knowing the counts on the host: the crop kernel reads
+        the boxes and the confidence-prefix count from device memory and skips the slots beyond it."""
         boxes, scores, labels, count, conf_count, gauss = det_out
         eng = self.detector.engine()
         emb_eng = self.classifier.encoder.engine()
@@ -244,12 +245,23 @@ class BatchedPipeline:
             ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
                             std=getattr(self.classifier.encoder, 'input_std', TANH_STD), count=conf_count[i:i + 1],
                             out=crops[i * dpi:(i + 1) * dpi])
-        # the embedder only runs over the valid crops (compaction = a gather of row indices)
+        return crops
+
+    def _select(self, crops, counts):
+        """The embedder only runs over the valid crops (compaction = a gather of row indices)."""
+        n, dpi = len(counts), self.detector.detections_per_img
+        eng = self.detector.engine()
         if sum(counts) == n * dpi:
             valid, sel = crops, None
         else:
             sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
             valid = crops.index_select(0, sel)
+        return valid, sel
+
+    def _crop_embed_match(self, images, det_out, counts, embed_batch=None):
+        """(kept for the dev tools) crops + selection with counts already on the host."""
+        crops = self._crops(images, det_out)
+        valid, sel = self._select(crops, counts)
         return crops, valid, sel
 
     def _finish(self, images, det_out, counts, emb, idx, sel):
@@ -280,8 +292,21 @@ class BatchedPipeline:
         t0 = mark()
         det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
         t1 = mark()
-        counts = det_out[4].tolist()                  # one host sync: the confidence-prefix counts
-        crops, valid, sel = self._crop_embed_match(images, det_out, counts)
+        # The one host synchronisation of a step -- the confidence-prefix counts, which size the embedder's batch -- is
+        # taken BESIDE the crop kernels, not before them: the counts go to pinned host memory right behind the detector,
+        # the crops (which read the counts on the device) are launched behind that copy, and the host wakes up as soon as
+        # the copy has landed, i.e. while the crops still run, and queues the embedder's launches behind them.
+        n = len(images)
+        pin = self.__dict__.setdefault('_count_pins', {})
+        if n not in pin:
+            pin[n] = torch.empty(n, dtype=torch.int32).pin_memory()
+        pin[n].copy_(det_out[4], non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        crops = self._crops(images, det_out)
+        copied.synchronize()
+        counts = pin[n].tolist()
+        valid, sel = self._select(crops, counts)
         t2 = mark()
         emb = self.classifier.encoder.engine().embed_packed(valid)
         t3 = mark()

@@ -607,3 +607,10 @@ def test_crop_resize_narrow_pixels(cuda):
     a = ops.crop_resize(img, boxes, 256, mode=1, mean=C.TANH_MEAN, std=C.TANH_STD)
     b = ops.crop_resize(img, boxes, 256, mode=2, mean=C.TANH_MEAN, std=C.TANH_STD)
     assert b.shape == (3, 256, 256, 4) and torch.equal(a[..., :4], b) and float(a[..., 3:].abs().max()) == 0.0
+    # the two-pixels-per-thread embedder kernel against the one-pixel f32 kernel (mode 0, itself checked against the oracle)
+    # followed by scale_to_tanh + normalisation on the host: the same fp32 expression, so the same bf16 bits
+    v = ops.crop_resize(img, boxes, 256, mode=0).cpu()
+    mean = torch.tensor(C.TANH_MEAN)[None, :, None, None]
+    std = torch.tensor(C.TANH_STD)[None, :, None, None]
+    want = ((v * 2.0 - 1.0 - mean) / std).to(torch.bfloat16).permute(0, 2, 3, 1)
+    assert torch.equal(b[..., :3].cpu(), want)
