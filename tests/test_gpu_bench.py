@@ -1,0 +1,42 @@
+"""bench.py's JSON contract on small inputs: every workload prints ONE line with the fields the driver reads, the roofline
+object, and (pipeline) the H2D-inclusive value, the parity object and the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'}
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_pipeline_line_small(cuda):
+    d = _run('--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--gallery', '128', '--no-peaks')
+    assert BASE <= set(d) and d['unit'] == 'images/s' and d['n_gpus'] == 1 and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'bf16' and 'workload' in d['config'] and d['value'] > 0
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert set(r['stages']) == {'detect', 'crop', 'embed', 'match'}
+    assert d['value_with_h2d'] > 0 and d['upload_mb_per_step'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    p = d['parity']
+    assert p['images'] == 4 and 0.5 < p['ap50_vs_oracle'] <= 1.0 and abs(p['G256_bf16']['top1_acc_delta_pt']) <= 2.0
+
+
+def test_detector_and_match_stress_lines(cuda):
+    d = _run('--workload', 'detector', '--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--no-cpu-baseline')
+    assert BASE <= set(d) and 'detector' in d['metric'] and d['roofline']['stages']['detect']['ms_per_step'] > 0
+    m = _run('--workload', 'match-stress', '--steps', '2')
+    assert BASE <= set(m) and m['unit'] == 'queries/s' and m['roofline']['bound'] == 'hbm' and len(m['roofline']['cases']) == 4
+    assert {(c['P'], c['D']) for c in m['roofline']['cases']} == {(200, 512), (200, 1024), (1600, 512), (1600, 1024)}
