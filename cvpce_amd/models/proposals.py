@@ -351,6 +351,8 @@ class GLNEngine:
         key = tuple(shapes)
         cache = self.__dict__.setdefault('_atlas_cache', {})
         if key not in cache:                 # (never inside a graph capture: the first call of a shape always runs eagerly)
+            if len(cache) > 64:              # datasets with thousands of distinct image sizes: keep the cache bounded
+                cache.clear()
             hc, wc, offs = self.atlas_layout(shapes)
             mask = torch.zeros(hc, wc, dtype=torch.uint8)
             for (h, w), (oy, ox) in zip(shapes, offs):
