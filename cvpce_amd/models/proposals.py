@@ -277,6 +277,14 @@ class GLNEngine:
         self.g_subnet = [P(b.conv) for b in subnet.blocks]
         self.tanh = subnet.tanh
 
+    def _keep(self, obj):
+        """A captured hipGraph holds raw pointers to engine-owned tensors (level masks, tile maps, atlas buffers, per-geometry
+        constants) that live in bounded caches: while a capture is being recorded every such object is also referenced from
+        the graph's entry, so that a cache eviction can never free memory a later replay reads."""
+        refs = self.__dict__.get('_capture_refs')
+        if refs is not None:
+            refs.append(obj)
+
     # -- stages ---------------------------------------------------------------
     @staticmethod
     def batch_geometry(images):
@@ -359,6 +367,7 @@ class GLNEngine:
                 mask[oy:oy + h, ox:ox + w] = 1
             cache[key] = (hc, wc, offs, mask.to(self.device), ops.atlas_tile_map(mask).to(self.device), int(mask.sum()))
         hc, wc, offs, mask, tile_map, npix = cache[key]
+        self._keep(cache[key])
         # Atlas buffers live in the engine, zero-filled ONCE: the kernels write level pixels (and zeros on the gap pixels of
         # the tiles they compute) and skip the tiles that lie wholly in a gap, so the gaps stay zero -- no memset, and about
         # 1/7 of the canvas tiles (the empty ones) are never scheduled.
@@ -369,6 +378,7 @@ class GLNEngine:
                 bufs.pop(next(iter(bufs)))
             bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=torch.bfloat16, device=self.device) for _ in range(5)]
         atlas, cls_a, cls_b, reg_a, reg_b = bufs[bkey]
+        self._keep(bufs[bkey])
         for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
             atlas[:, oy:oy + h, ox:ox + w] = f
 
@@ -453,6 +463,7 @@ class GLNEngine:
             torch.cuda.current_stream().synchronize()
             cache[key] = (image_hw, ratios)
         image_hw, ratios = cache[key]
+        self._keep(cache[key])
         return ops.detect_postprocess(logits, regs, grids, strides, self.base_anchors, image_hw, ratios,
                                       self.num_anchors, num_classes, TOPK_CANDIDATES, SCORE_THRESH, NMS_THRESH,
                                       BBOX_XFORM_CLIP, detections_per_img, conf_thresh)
@@ -484,10 +495,18 @@ class GLNEngine:
             self.transform(images, out=static_in)
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            # (thread-local capture mode: other threads -- e.g. an RCCL watchdog polling its events -- may keep issuing HIP calls)
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                static_out = self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
-            entry.update(graph=g, static_in=static_in, static_out=static_out)
+            self._capture_refs = []            # engine-owned tensors the captured kernels point at (see _keep)
+            try:
+                # (thread-local capture mode: other threads -- e.g. an RCCL watchdog polling its events -- may keep issuing HIP calls)
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    static_out = self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
+            except Exception:
+                # e.g. a host-side cache was evicted since the first call and would have to be refilled (an upload) inside the
+                # capture: run this call eagerly -- which refills the caches -- and try the capture again next time
+                self.__dict__.pop('_capture_refs', None)
+                torch.cuda.synchronize()
+                return self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
+            entry.update(graph=g, static_in=static_in, static_out=static_out, keepalive=self.__dict__.pop('_capture_refs'))
         else:
             self.transform(images, out=entry['static_in'])
         entry['graph'].replay()

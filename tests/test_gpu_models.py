@@ -412,3 +412,23 @@ def test_detector_full_size_properties(cuda, gln_model):
         assert float(bx.min()) >= 0 and float(bx[:, 2].max()) <= 2048 and float(bx[:, 3].max()) <= 2048
         assert bool((bx[:, 2] >= bx[:, 0]).all()) and bool((bx[:, 3] >= bx[:, 1]).all())
 
+
+
+def test_detector_graph_survives_cache_eviction(cuda, gln_model):
+    """The captured detector graph keeps the engine-owned tensors it points at (level masks, tile maps, atlas buffers,
+    per-geometry constants) alive: evicting every host-side cache and thrashing the allocator must not change a replay."""
+    from cvpce_amd import synthetic
+    det, _ = gln_model
+    eng = det.engine()
+    imgs = [synthetic.shelf_image(90 + i, 512, 640).to(cuda) for i in range(2)]
+    a = eng.detect(imgs, 1, 200)          # eager
+    b = eng.detect(imgs, 1, 200)          # capture + replay
+    for name in ('_atlas_cache', '_atlas_bufs', '_pp_cache'):
+        eng.__dict__.get(name, {}).clear()
+    junk = [torch.full((1 << 22,), 7.0, device=cuda) for _ in range(64)]    # reuse whatever memory became free
+    del junk
+    torch.cuda.empty_cache()
+    c = eng.detect(imgs, 1, 200)          # replay
+    torch.cuda.synchronize()
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
