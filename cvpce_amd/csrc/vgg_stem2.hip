@@ -23,7 +23,7 @@
 #include "../../include/cvpce_amd.h"
 
 // compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 no initial de-phasing,
-// 2 raised priority in the conv1_2 phase, 4 NO raised priority outside it (the shipped default raises it: -8 %), 8 skip conv1_1, 16 skip the conv1_2 MFMAs
+// 2 raised priority in the conv1_2 phase, 4 NO raised priority outside it (the shipped default raises it: -8 %), 8 skip conv1_1, 16 skip the conv1_2 MFMAs, 32 no weight-fragment LDS reads after the first three K-steps, 64 no pixel-fragment reads, 128 in-kernel stamps (below)
 #ifndef CVPCE_DBG
 #define CVPCE_DBG 0
 #endif
@@ -59,6 +59,18 @@ __device__ __forceinline__ int s2_a1_off(int py, int px, int chunk) {
 }
 
 typedef __attribute__((address_space(3))) char lds_char;
+
+#if (CVPCE_DBG & 128)
+// diagnostic build only (tools/ablate.sh vgg_stem2 128; tools/dev/stem_stamps.py): s_memtime stamps of one wave of each team of
+// workgroup 0 at the phase boundaries of its first 16 tiles.  No output value depends on them.
+__device__ unsigned long long cvpce_stem_stamps[2][16][6];
+extern "C" int cvpce_debug_stem_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cvpce_stem_stamps), sizeof(cvpce_stem_stamps)) == hipSuccess ? 0 : 2;
+}
+#define S2_STAMP(I) if (blockIdx.x == 0 && wid == 0 && lane == 0 && it_ < 16) cvpce_stem_stamps[team][it_][I] = __builtin_amdgcn_s_memtime();
+#else
+#define S2_STAMP(I)
+#endif
 
 // barrier among the 4 waves of a team: arrive = ds_add on the team's LDS counter (after this wave's LDS traffic has
 // drained), wait = poll until all 4 arrivals of this round are in.  `target` counts arrivals expected so far.
@@ -167,7 +179,10 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
         for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
+    int it_ = -1;
     for (; tile < a.ntiles; tile += stride) {
+        ++it_;
+        S2_STAMP(0)
         const int n = tile / (a.tiles_x * a.tiles_y);
         const int rem = tile - n * (a.tiles_x * a.tiles_y);
         const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -225,7 +240,9 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
                     }
             }
         }
+        S2_STAMP(1)
         team_barrier(cnt_addr, bar_target, lane);
+        S2_STAMP(2)
         if (next < a.ntiles) store_patch();             // IN is free again: stage the next tile's input
 
         // ================= phase 2: conv1_2 (9 taps x 4 K-steps) out of LDS =================
@@ -244,10 +261,13 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
             const int tap = (S) >> 2, kk = (S) & 3;                                                            \
             const int kh = tap / 3, kw = tap - kh * 3;                                                         \
             const int chunk = kk * 2 + lh;                                                                     \
+            if (!(CVPCE_DBG & 32) || (S) < 3) {                                                                \
             _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                 \
                 const int row = tap * 64 + mt * 32 + lr;                                                       \
                 af[SLOT][mt] = *reinterpret_cast<const bf16x8*>(W2 + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); \
             }                                                                                                  \
+            }                                                                                                  \
+            if (!(CVPCE_DBG & 64) || (S) < 3)                                                                  \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
                 bfr[SLOT][nt] = *reinterpret_cast<const bf16x8*>(A1 + ((rd2[nt][kw] ^ (unsigned)(((2 * kk) ^ (kh & 1)) << 4)) + (unsigned)((kh * S2_P1 + kw) * 128))); \
         }
@@ -269,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef S2_LOAD
+        S2_STAMP(3)
         if (CVPCE_DBG & 2) __builtin_amdgcn_s_setprio(0);
         if (!(CVPCE_DBG & 4)) __builtin_amdgcn_s_setprio(2);
         // epilogue: 2x2 max over the quad's 4 lanes (DPP), ReLU.  After pooling the 4 lanes of a quad hold the
@@ -304,7 +325,9 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
             bf16_t* dst = a.out + ((size_t)(n * Ho + oyp) * Wo + oxp) * 64 + lh * 32 + sub * 8;
             *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
         }
+        S2_STAMP(4)
         team_barrier(cnt_addr, bar_target, lane);        // A1 is free again; the next input patch is visible
+        S2_STAMP(5)
     }
 }
 

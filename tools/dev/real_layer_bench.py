@@ -31,6 +31,18 @@ if mode == 'capture':
 else:
     want = sys.argv[2].split(',') if len(sys.argv) > 2 else names
     convs = [(k, pc) for k, pc in eng.plan if k in ('conv', 'conv_pool')]
+    if 'stem' in want:
+        x = torch.load('/tmp/real_stem_in.pt').to(dev)
+        for _ in range(3):
+            ops.vgg_stem(x, eng.stem)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.vgg_stem(x, eng.stem)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f'stem {ms:.3f} ms {eng.stem.flops_per_pixel * 256 * 65536 / ms / 1e9:7.1f} TF', flush=True)
     for nm, (kind, pc) in zip(names, convs):
         if nm not in want:
             continue
