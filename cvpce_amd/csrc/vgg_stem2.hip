@@ -255,7 +255,10 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[mt][0][4 * g + j] = b[j]; acc[mt][1][4 * g + j] = b[j]; }
             }
-        bf16x8 af[3][2], bfr[3][2];
+#ifndef S2_DEPTH
+#define S2_DEPTH 2            // K-steps the fragment reads run ahead of the MFMAs (S2_DEPTH + 1 register slots)
+#endif
+        bf16x8 af[S2_DEPTH + 1][2], bfr[S2_DEPTH + 1][2];
 #define S2_LOAD(S, SLOT)                                                                                       \
         {                                                                                                      \
             const int tap = (S) >> 2, kk = (S) & 3;                                                            \
@@ -274,18 +277,18 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
         // fragments run TWO K-steps ahead of the MFMAs (3 register slots); sched_barrier pins that order
         if (!(CVPCE_DBG & 4)) __builtin_amdgcn_s_setprio(0);
         if (CVPCE_DBG & 2) __builtin_amdgcn_s_setprio(2);
-        S2_LOAD(0, 0)
-        S2_LOAD(1, 1)
+#pragma unroll
+        for (int s = 0; s < S2_DEPTH; ++s) S2_LOAD(s, s)
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (s + 2 < 36) S2_LOAD(s + 2, (s + 2) % 3)
+            if (s + S2_DEPTH < 36) S2_LOAD(s + S2_DEPTH, (s + S2_DEPTH) % (S2_DEPTH + 1))
             __builtin_amdgcn_sched_barrier(0);
             if (!(CVPCE_DBG & 16))
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % 3][mt], bfr[s % 3][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % (S2_DEPTH + 1)][mt], bfr[s % (S2_DEPTH + 1)][nt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef S2_LOAD
