@@ -13,6 +13,7 @@ FrozenBN/BN and fused residual / upsample-add / ReLU epilogues, LDS radix-select
 top-k, bitmask NMS.  There is no CPU path: tensors must live on a HIP device.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -33,6 +34,7 @@ USE_HEAD_ATLAS = True   # head towers on ONE atlas of the 5 pyramid levels (one 
 N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
 USE_DETECT_GRAPH = True   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
 MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image)
+USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
 
 
 # ---------------------------------------------------------------------------
@@ -241,6 +243,7 @@ class GLNEngine:
             return P(conv, scale=s, shift=b)
 
         self.stem = fold(body.conv1, body.bn1)
+        self.stem_fused = ops.PackedGlnStem(body.conv1.weight, *body.bn1.affine(), device=device) if tuple(body.conv1.weight.shape) == (64, 3, 7, 7) else None
         self.layers = []
         for li in range(4):
             blocks = []
@@ -304,8 +307,11 @@ class GLNEngine:
         return batch, sizes, rs
 
     def body(self, x):
-        x = ops.conv2d(x, self.stem, act=1)
-        x = ops.maxpool2d(x, 3, 2, 1)
+        if USE_FUSED_STEM and self.stem_fused is not None:
+            x = ops.gln_stem(x, self.stem_fused)
+        else:
+            x = ops.conv2d(x, self.stem, act=1)
+            x = ops.maxpool2d(x, 3, 2, 1)
         feats = []
         for blocks in self.layers:
             for c1, c2, c3, ds in blocks:

@@ -215,6 +215,38 @@ class PackedStem:
         self.flops_per_pixel = 2.0 * 64 * (27 + 576)
 
 
+class PackedGlnStem:
+    """conv 7x7/2 (3->64) with its FrozenBatchNorm folded in, in the MFMA fragment order of cvpce_gln_stem_fused."""
+
+    def __init__(self, weight, scale, shift, device='cuda'):
+        w = weight.detach().to(torch.float32).cpu() * scale.detach().to(torch.float32).cpu()[:, None, None, None]
+        assert tuple(w.shape) == (64, 3, 7, 7)
+        slots = torch.zeros(64, 7, 8, 4)                       # (cout, kh, kw slot, channel slot)
+        slots[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        # [ct][kh][h][lh][r][kw_local 2][c 4]: kw = 4h + 2lh + kw_local
+        f = slots.reshape(2, 32, 7, 2, 2, 2, 4).permute(0, 2, 3, 4, 1, 5, 6)
+        self.w_frag = f.reshape(2, 14, 64, 8).contiguous().to(BF16).to(device)
+        self.bias = shift.detach().to(torch.float32).to(device)
+
+
+def gln_stem(x, ps):
+    """x: (N,H,W,8) bf16 transformed batch -> (N,Hp,Wp,64) bf16 = maxpool3x3/2(relu(bn(conv7x7/2(x))))."""
+    _need_cuda(x)
+    assert x.dtype == BF16 and x.is_contiguous() and x.shape[3] == 8
+    n, h, w, _ = x.shape
+    hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((n, (hc - 1) // 2 + 1, (wc - 1) // 2 + 1, 64), dtype=BF16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.gln_stem_fused(x, ps.w_frag, ps.bias, out)
+    if prof is not None:
+        e1.record()
+        prof.records.append(('gln_stem_kernel', 2.0 * n * hc * wc * 64 * 147, e0, e1))
+    return out
+
+
 def atlas_tile_map(mask, tile=16):
     """(H,W) uint8 level mask (host or device) -> int32 device tensor of the 16x16 tiles that contain a level pixel, (ty << 16) | tx."""
     m = mask.cpu().bool()

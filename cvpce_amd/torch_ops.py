@@ -86,6 +86,12 @@ def _vgg_stem_fused(x, w1, b1, w2, b2, out):
     check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(w1), _p(b1), _p(w2), _p(b2), _p(out), n, h, w, _stream()), 'cvpce_vgg_stem_fused')
 
 
+@_op('gln_stem_fused(Tensor x, Tensor w_frag, Tensor bias, Tensor(a!) out) -> ()')
+def _gln_stem_fused(x, w_frag, bias, out):
+    n, h, w, c = x.shape
+    check(lib.cvpce_gln_stem_fused(_p(x), _p(w_frag), _p(bias), _p(out), n, h, w, _stream()), 'cvpce_gln_stem_fused')
+
+
 @_op('maxpool2d_nhwc(Tensor x, Tensor(a!) out, int k, int stride, int pad) -> ()')
 def _maxpool2d_nhwc(x, out, k, stride, pad):
     n, h, w, c = x.shape

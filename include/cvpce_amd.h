@@ -60,6 +60,16 @@ int cvpce_conv1x1_nhwc_bf16(const void* in, const void* wgt, const float* bias, 
 int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
                          const float* b2, void* out, int N, int H, int W, void* stream);
 
+/* Fused detector stem: torchvision resnet50 conv1 (7x7, stride 2, pad 3, 3 -> 64) + FrozenBatchNorm2d (folded into
+ * w/bias) + ReLU + MaxPool2d(3, 2, 1), reached from cvpce/models/proposals.py:202-216 (resnet_fpn_backbone) via
+ * GaussianLayerNetwork.forward (proposals.py:166-168).  in: [N][H][W][8] bf16 as cvpce_gln_transform writes it (channels
+ * 0..2 used).  w_frag: bf16 [2][14][64][8], the 64 x (7 kh x 8 kw slots x 4 channels) weights in MFMA fragment order:
+ * entry [ct][kh*2 + h][lh*32 + r][j] = w[ct*32 + r][c = j%4][kh][kw = 4h + 2lh + j/4], zero for kw = 7 and c = 3.
+ * bias: 64 floats.  out: [N][Hp][Wp][64] bf16 with Hc = (H-1)/2 + 1, Hp = (Hc-1)/2 + 1 (same for W).  Numerics: the
+ * convolution output is rounded to bf16 before pooling, exactly as conv2d_nhwc_bf16 followed by maxpool2d_nhwc_bf16. */
+int cvpce_gln_stem_fused(const void* in_nhwc8, const void* w_frag, const float* bias, void* out, int N, int H, int W,
+                         void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution with Cin % 64 == 0 and the input halo patch resident in LDS (VGG16 conv2_2 ..
  * conv5_3, RetinaNet head / FPN 3x3s): same operands, weight layout and numerics as cvpce_conv2d_nhwc_bf16; any H, W
  * (ragged 16x16 tiles are masked; H, W even when pooling), Cout % 8 == 0;

@@ -414,6 +414,43 @@ def test_vgg_stem_rejects_bad_shapes(cuda):
         ops.vgg_stem(torch.zeros(1, 24, 16, 8, dtype=BF, device=cuda), ps)     # H not a multiple of 16
 
 
+@pytest.mark.parametrize('n,h,w', [(2, 64, 64), (1, 800, 608), (3, 37, 51), (1, 7, 9), (2, 130, 66), (1, 1, 1)])
+def test_gln_stem_fused_parity(cuda, n, h, w):
+    """conv7x7/2 + FrozenBN + ReLU + maxpool3x3/2 in one launch against the oracle ops on the same bf16-rounded operands
+    (the convolution output is rounded to bf16 before pooling, as the unfused schedule stores it), and against the unfused
+    HIP schedule (generic conv + pool kernels) within one bf16 ulp (the two kernels accumulate K in different orders).
+    Odd and tiny sizes exercise every border: conv padding, pool padding, partial tiles."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(zlib.crc32(f'glnstem/{n}/{h}/{w}'.encode()))
+    x = r16(torch.randn(n, 3, h, w, generator=g))
+    wt = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.2
+    wf = r16(wt * scale[:, None, None, None])
+    ref = F.max_pool2d(r16(F.relu(F.conv2d(x, wf, shift, stride=2, padding=3))), 3, 2, 1)
+    ps = ops.PackedGlnStem(wt, scale, shift, device=cuda)
+    xin = nhwc(x).to(cuda)
+    got = ops.gln_stem(xin, ps)
+    assert nchw(got).shape == ref.shape
+    assert rel_err(nchw(got), ref) < 1e-2, rel_err(nchw(got), ref)
+    pc = ops.PackedConv(wt, None, 2, 3, scale=scale, shift=shift, device=cuda)
+    unf = ops.maxpool2d(ops.conv2d(xin, pc, act=1), 3, 2, 1)
+    assert unf.shape == got.shape
+    assert (unf.float() - got.float()).abs().max() <= 2 ** -7 * unf.float().abs().max()
+    assert (unf != got).float().mean() < 0.02            # and almost everywhere bit-identical
+
+
+def test_gln_stem_channel3_ignored(cuda):
+    """Whatever sits in channels 3..7 of the NHWC8 input must not reach the output."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(5)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+    ps = ops.PackedGlnStem(wt, torch.ones(64), torch.zeros(64), device=cuda)
+    x = torch.randn(1, 40, 40, 8, generator=g).to(BF)
+    clean = x.clone(); clean[..., 3:] = 0
+    assert torch.equal(ops.gln_stem(x.to(cuda), ps), ops.gln_stem(clean.to(cuda), ps))
+
+
 HALO_CASES = [  # n, cin, h, w, cout, pool
     (4, 128, 128, 128, 128, True),     # VGG conv2_2 shape (TC = 128, pooled)
     (16, 128, 64, 64, 256, False),     # conv3_1
