@@ -34,6 +34,7 @@ USE_HEAD_ATLAS = True   # head towers on ONE atlas of the 5 pyramid levels (one 
 N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
 USE_DETECT_GRAPH = True   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
 MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image)
+USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
 USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
 
 
@@ -315,23 +316,52 @@ class GLNEngine:
         feats = []
         for blocks in self.layers:
             for c1, c2, c3, ds in blocks:
-                identity = ops.conv2d(x, ds) if ds is not None else x
+                # the projection shortcut of a stage's first block is independent of conv1 -> conv2: beside them
+                identity, joined = self._beside(2, lambda: ops.conv2d(x, ds)) if ds is not None else (x, None)
                 y = ops.conv2d(x, c1, act=1)
                 y = ops.conv2d(y, c2, act=1)
+                if joined is not None:
+                    torch.cuda.current_stream().wait_event(joined)
                 x = ops.conv2d(y, c3, act=1, residual=identity)
             feats.append(x)
         return feats  # C2..C5
 
     def fpn(self, c3, c4, c5):
+        # the top-down chain i5 -> i4 -> i3 -> p3 is the critical path; the output convs of the coarser levels and P6 / P7
+        # (small maps, latency-bound launches) hang off it and run beside it
+        def coarse(i5):
+            p5 = ops.conv2d(i5, self.outer[2])
+            p6 = ops.conv2d(p5, self.p6)
+            return p5, p6, ops.conv2d(ops.relu(p6), self.p7)
+
         i5 = ops.conv2d(c5, self.inner[2])
-        p5 = ops.conv2d(i5, self.outer[2])
+        (p5, p6, p7), coarse_done = self._beside(2, lambda: coarse(i5))
         i4 = ops.conv2d(c4, self.inner[1], residual=i5, res_mode=2)
-        p4 = ops.conv2d(i4, self.outer[1])
+        p4, p4_done = self._beside(3, lambda: ops.conv2d(i4, self.outer[1]))
         i3 = ops.conv2d(c3, self.inner[0], residual=i4, res_mode=2)
         p3 = ops.conv2d(i3, self.outer[0])
-        p6 = ops.conv2d(p5, self.p6)
-        p7 = ops.conv2d(ops.relu(p6), self.p7)
+        for ev in (coarse_done, p4_done):
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
         return [p3, p4, p5, p6, p7]
+
+    def _beside(self, k, fn):
+        """Run `fn` (launches whose inputs are ready on the current stream) on side stream k, concurrently with what the
+        caller enqueues next.  -> (result, event the consumer stream must wait on | None when side streams are off).  Works
+        the same eagerly and inside a hipGraph capture (the fork / join become graph dependencies)."""
+        if not (self.side_streams and USE_SIDE_BRANCHES):
+            return fn(), None
+        main, side = torch.cuda.current_stream(), self.side_streams[k % len(self.side_streams)]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            out = fn()
+            for t in (out if isinstance(out, tuple) else (out,)):
+                t.record_stream(main)
+            done = torch.cuda.Event()
+            done.record(side)
+        return out, done
 
     def gaussian_branch(self, c2, p3):
         x = ops.conv2d(c2, self.g_lateral, residual=p3, res_mode=2)       # lateral(C2) + up2(P3)
@@ -522,10 +552,13 @@ class GLNEngine:
     def _detect_tail(self, batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates):
         c2, c3, c4, c5 = self.body(batch)
         feats = self.fpn(c3, c4, c5)
-        gauss = self.gaussian_branch(c2, feats[0])
+        # the Gaussian branch (8 small convs, proposals.py:65-107) depends on C2 and P3 only: it runs beside the heads
+        gauss, gauss_done = self._beside(1, lambda: self.gaussian_branch(c2, feats[0]))
         cls, reg = self.heads_atlas(feats) if USE_HEAD_ATLAS else self.heads(feats)
         out = self.postprocess(cls, reg, tuple(batch.shape[1:3]), resized, original, num_classes,
                                detections_per_img, conf_thresh)
+        if gauss_done is not None:
+            torch.cuda.current_stream().wait_event(gauss_done)
         gauss = gauss.permute(0, 3, 1, 2)  # (N,1,h,w) view of the NHWC buffer (C == 1)
         if want_intermediates:
             return out + (gauss,), {'batch': batch, 'c': (c2, c3, c4, c5), 'features': feats, 'cls': cls, 'reg': reg}
