@@ -26,6 +26,11 @@ INPUT_SIZE = 256
 USE_FUSED_STEM = True   # A/B switch (tests compare the fused stem against the unfused conv kernels)
 import os as _os
 MAX_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 256))  # crops per kernel schedule pass (keeps every NHWC tensor < 2^31 elements)
+# ... with the fused stem the largest tensor of a pass is conv2_x's output (128 x 128 x 128 per crop), so a pass can take 3x as
+# many crops under the 4 GB buffer-offset limit.  Whole multiples of 256 keep every layer's workgroup count a multiple of the CU
+# count (conv5_x: two workgroups per crop); measured on the pipeline bench, same call: 256 -> 156.4, 512 -> 158.1, 768 -> 158.6,
+# 800 -> 157.6, 400 -> 153.5, 200 -> 150.6 images/s.
+FUSED_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 768))
 
 
 def _vgg_features(cfg, batch_norm):
@@ -88,7 +93,7 @@ class MACVGGEngine:
         batch: crops per pass of the kernel schedule (default MAX_EMBED_BATCH; a host that runs on fewer CUs passes that
         CU count so that the persistent kernels' tile counts stay whole multiples of their grid)."""
         outs, outs_bf = [], []
-        step = batch or MAX_EMBED_BATCH
+        step = batch or (FUSED_EMBED_BATCH if self.stem is not None and x.shape[1] * x.shape[2] <= INPUT_SIZE * INPUT_SIZE else MAX_EMBED_BATCH)
         plan = self.plan + [('desc', None)]            # the second descriptor: amax of the last map (classification.py:48-49)
         for s in range(0, x.shape[0], step):
             xb = x[s:s + step]
