@@ -19,8 +19,14 @@ out = {}
 for kind in ('fetch', 'write'):
     f = glob.glob(f'{root}/gpurun_out/{pmc}/{kind}/*/*_counter_collection.csv')[0]
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+    rows_ = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
+    # only the launches of the LAST pipeline pass (= one timed step of bench.py: it starts with the 8 transform launches of the
+    # step's images); the gallery build and the warm-up pass launch the same kernels on other batch sizes
+    marks = [int(r['Dispatch_Id']) for r in rows_ if r['Kernel_Name'].startswith('gln_transform_kernel')]
+    first = marks[-8] if len(marks) >= 8 else 0
+    for r in rows_:
+        if int(r['Dispatch_Id']) >= first:
+            agg[r['Kernel_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         out.setdefault(k, {})[kind] = (len(v), sum(v))
 rows = []
@@ -30,7 +36,7 @@ for k, d in out.items():
 rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
 byname = collections.defaultdict(lambda: [0, 0.0, 0.0])
 with open(f'{root}/profiles/{tag}_pmc_hbm_traffic.md', 'w') as fo:
-    fo.write(f'# HBM traffic per launch, bench.py --steps 1 --warmup 1 (gallery build + 2 pipeline passes), MI355X, {tag} build\n\n')
+    fo.write(f'# HBM traffic per launch over ONE step of bench.py (the last pipeline pass of `--steps 1 --warmup 1`: 8 images, 1600 crops), MI355X, {tag} build\n\n')
     fo.write('Two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; KB units), averaged per launch.\n')
     fo.write('FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of wide reads at 64 B); WRITE_SIZE as is.\n\n')
     fo.write('| kernel | launches | read MB/launch | write MB/launch | total MB/launch |\n|---|---|---|---|---|\n')
