@@ -20,6 +20,9 @@
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 
+#ifndef CVPCE_DBG
+#define CVPCE_DBG 0          // compile-time ablations (tools/ablate.sh): 4 no patch DMA after the first two sub-chunks, 8 no weight
+#endif                       // loads in the loop, 16 no stores (runtime-false predicate), 32 no fragment reads; timing only
 #define G3_TH 16
 #define G3_TW 32
 #define G3_PW 34
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     const int nsub = 2 * nchunks;
     auto issue_next_patch = [&]() {
         if (pi < total_sub) {
-            issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
+            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
             ++pi;
             if (++pi_buf == 3) pi_buf = 0;
             if (++pi_c == nsub) {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // ROW STREAMING (see conv3x3_halo2.hip): step T = sub-chunk * 3 + kw of a body (0..5) holds the weights of the three
     // taps (kh, kw) of its 32 channels, reads each of the 18 patch rows once and issues up to 6 MFMAs on it.
 #define G3_LOAD_A(T, SBASE)                                                                                    \
-    {                                                                                                          \
+    if constexpr (!(CVPCE_DBG & 8)) {                                                                          \
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + (kh_ * 3 + (T) % 3) * 128 + ((T) / 3) * 64, 0); \
@@ -163,11 +166,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #define G3_SET_E(T, BUFB) { e0 = c3[(T) % 3] + (BUFB); }
     // read patch row P of step T into ring slot (P + 2 T) & 3 (a step has 18 rows, 18 = 2 mod 4)
 #define G3_READ(T, P)                                                                                          \
+    if constexpr (!(CVPCE_DBG & 32))                                                                           \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[((P) + 2 * (T)) & 3]) : "v"(e0), "n"(((P) * G3_PW + (T) % 3) * 64));
     // the MFMAs of patch row P: output rows P (kh = 0), P-1 (kh = 1), P-2 (kh = 2) where they exist
 #define G3_ROW(T, P)                                                                                           \
     {                                                                                                          \
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[((P) + 2 * (T)) & 3]));                                 \
+        if constexpr (!(CVPCE_DBG & 32)) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[((P) + 2 * (T)) & 3]));  \
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
                 _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                            \
@@ -183,7 +187,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // rows 0, 1 of step T + 1 from the same buffer
     // the sub-chunk hand-off: this wave is done with the PREVIOUS sub-chunk's buffer and (vmcnt) its own pieces of the NEXT
     // sub-chunk's patch have landed -- at most the 6 weight loads just issued are younger than those pieces; then the DMA
-    // of the sub-chunk after the next one goes into the buffer the previous one used
+    // of the sub-chunk after the next one goes into the buffer the previous one used.
+    // (Tried: issuing that DMA one step later, BEHIND the next weight loads, so that the in-order return of the loads gives
+    // the pieces two steps instead of one before a weight wait can stall on them -- no gain, conv2_1 0.70 -> 0.72 ms.)
 #define G3_HANDOFF()                                                                                           \
     {                                                                                                          \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                                 r[4 * mt + j] = fmaxf(v, fmaxf(up, dn));
                             }
                         }
-                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout) {
+                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[0], r[1], r[2], r[3]}));
                         const uint2 h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { r0[j] = relu_bits(r0[j]); r1[j] = relu_bits(r1[j]); }
                     }
-                    if (store_lane && co < a.Cout) {
+                    if (store_lane && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r0)), h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r1));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
