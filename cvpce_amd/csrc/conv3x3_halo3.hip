@@ -42,8 +42,23 @@ struct Halo3Args {
     unsigned in_bytes, wgt_bytes;
 };
 
+// diagnostic build only (tools/ablate.sh conv3x3_halo3 128; tools/dev/halo3_stamps.py): s_memtime ticks two waves of one workgroup
+// spend in [weights wait at the end of a step, hand-off vmcnt, hand-off barrier, epilogue, whole loop]; [5] = timed steps
+__device__ unsigned long long cvpce_halo3_stamps[2][6];
+extern "C" int cvpce_debug_halo3_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cvpce_halo3_stamps), sizeof(cvpce_halo3_stamps)) == hipSuccess ? 0 : 2;
+}
+#if CVPCE_DBG & 128
+#define G3_TIC() const unsigned long long tic_ = __builtin_amdgcn_s_memtime();
+#define G3_TOC(I) st_[I] += __builtin_amdgcn_s_memtime() - tic_;
+#else
+#define G3_TIC()
+#define G3_TOC(I)
+#endif
+
 template <bool POOL>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
     constexpr int TC = 128, NB = 16, NG = 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -192,8 +207,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // the pieces two steps instead of one before a weight wait can stall on them -- no gain, conv2_1 0.70 -> 0.72 ms.)
 #define G3_HANDOFF()                                                                                           \
     {                                                                                                          \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
-        __builtin_amdgcn_s_barrier();                                                                          \
+        { G3_TIC() asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); G3_TOC(1) }                                \
+        { G3_TIC() __builtin_amdgcn_s_barrier(); G3_TOC(2) }                                                   \
         issue_next_patch();                                                                                    \
     }
 #define G3_STEP(T)                                                                                             \
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         G3_SET_E((T) + 1, bufb)                                                                                \
         G3_READ((T) + 1, 0) G3_ROW(T, 16)                                                                      \
         G3_READ((T) + 1, 1) G3_ROW(T, 17)                                                                      \
+        if constexpr (CVPCE_DBG & 128) { G3_TIC() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G3_TOC(0) st_[5] += 1; } \
     }
     // last step of a sub-chunk (T = 2 or 5) with the hand-off.  After the last sub-chunk the barrier, the reads and the
     // weight loads still run, on valid but unused data, so that the loop body has one shape.
@@ -246,6 +262,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     G3_READ(0, 1)
 
     const int lp = lane & 15;
+#if CVPCE_DBG & 128
+    const unsigned long long loop0_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int cc = 0; cc < total_chunks; ++cc) {
         asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
         G3_STEP(0) G3_STEP(1)
@@ -257,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         if (cchunk + 1 == nchunks) {
             // ---- epilogue of this tile (the next tile's patch, weights and first fragments are already in flight) ----
             const int n = t_n, ty = t_ty, tx = t_tx, ct = t_ct;
+            G3_TIC()
             f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
             load_bias(n_ct, nbias);
             const int col = g3_col(lp);
@@ -317,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NB; ++nt) acc[mt][nt] = nbias[mt];
+            G3_TOC(3)
             cchunk = 0;
             ++seq;
             if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct);
@@ -327,6 +348,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         sb_next = wbase(n_ct, (cchunk + 1 < nchunks) ? cchunk + 1 : 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
+#if CVPCE_DBG & 128
+    st_[4] = __builtin_amdgcn_s_memtime() - loop0_;
+    if (blockIdx.x == 3 && (wid == 0 || wid == 5) && lane == 0)
+        for (int i = 0; i < 6; ++i) cvpce_halo3_stamps[wid ? 1 : 0][i] = st_[i];
+#endif
 #undef G3_STEP_HANDOFF
 #undef G3_STEP
 #undef G3_HANDOFF
