@@ -14,6 +14,15 @@ from . import datautils, ops
 from .models.classification import TANH_MEAN, TANH_STD
 
 
+# Crops / gallery images handed to the encoder per call.  The reference's `batch_size` (8 in cvpce/cli/eval.py, 32 by default) bounds
+# the memory of ONE forward pass on its GPU; here a pass over 8 crops would leave 7/8 of the chip idle (a conv5 layer is two
+# workgroups per crop), and the per-crop results do not depend on what else is in the batch (no batch statistics; tests assert
+# bit-identical embeddings), so `batch_size` is treated as a lower bound and calls are coalesced up to this many images.
+ENGINE_BATCH = 1024
+INDEX_BATCH = 64      # build_index: gallery images per pass (the host side -- reading and staging f32 images -- dominates there)
+PINNED_STAGING = True  # build_index: persistent pinned double buffer instead of torch.stack + pin_memory per pass
+
+
 def _nondegenerate(boxes):
     b = boxes.to(torch.long)
     return ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
@@ -104,21 +113,37 @@ class Classifier:
     def build_index(self, sample_set, verbose=False):
         """production.py:36-48.  Gallery images are already in [-1,1] (datautils.py:446): no scale_to_tanh."""
         chunks, annotations, imgs = [], [], []
-        pin = torch.cuda.is_available()
+        step = max(self.batch_size, INDEX_BATCH)
+        staging = []          # two pinned host buffers (step, C, H, W) + the event after which each may be refilled
 
         def flush():
-            if imgs:
-                batch = torch.stack(imgs)
-                batch = (batch.pin_memory() if pin and not batch.is_cuda else batch).to(device=self.device, non_blocking=True)
-                chunks.append(self.encoder(batch).detach().to(device=self.emb_device))
-                imgs.clear()
+            if not imgs:
+                return
+            first = imgs[0]
+            if first.is_cuda or not torch.cuda.is_available() or not PINNED_STAGING:
+                batch = torch.stack(imgs).to(device=self.device)
+            else:
+                # one pass from the dataset's tensors into a persistent pinned buffer, async upload; the two buffers alternate
+                # so that the host fills one while the other's upload / encoder pass is in flight
+                if not staging or staging[0][0].shape[1:] != first.shape or staging[0][0].dtype != first.dtype:
+                    staging[:] = [[torch.empty((step,) + tuple(first.shape), dtype=first.dtype).pin_memory(), None] for _ in range(2)]
+                staging.append(staging.pop(0))
+                buf, ev = staging[0]
+                if ev is not None:
+                    ev.synchronize()
+                torch.stack(imgs, out=buf[:len(imgs)])
+                batch = buf[:len(imgs)].to(device=self.device, non_blocking=True)
+                staging[0][1] = torch.cuda.Event()
+                staging[0][1].record()
+            chunks.append(self.encoder(batch).detach().to(device=self.emb_device))
+            imgs.clear()
 
         for i, item in enumerate(self._gallery_items(sample_set)):
             imgs.append(item[0])
             annotations.append(item[-1])
-            if len(imgs) == self.batch_size:
-                if verbose and (i // self.batch_size) % 100 == 0:
-                    print(i // self.batch_size)
+            if verbose and (i + 1) % self.batch_size == 0 and (i // self.batch_size) % 100 == 0:
+                print(i // self.batch_size)
+            if len(imgs) >= step:
                 flush()
         flush()
         if chunks:
@@ -143,8 +168,9 @@ class Classifier:
         """production.py:57-74: images (P,3,256,256) in [0,1] -> list[list[str]] (P x k)."""
         res, embs = [], []
         eng = self.encoder.engine()
-        for i in range(0, len(images), self.batch_size):
-            batch = images[i:i + self.batch_size].to(device=self.device)
+        step = max(self.batch_size, ENGINE_BATCH)
+        for i in range(0, len(images), step):
+            batch = images[i:i + step].to(device=self.device)
             packed = ops.pack_embed_input(batch, True, getattr(self.encoder, 'input_mean', TANH_MEAN),
                                           getattr(self.encoder, 'input_std', TANH_STD))  # scale_to_tanh + the encoder's own normalisation, fused
             emb = eng.embed_packed(packed)

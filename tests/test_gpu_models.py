@@ -239,6 +239,29 @@ def test_index_save_load_roundtrip(cuda, vgg_model, tmp_path):
     assert clf.classify(torch.empty(0, 3, 256, 256, device=cuda)) == []
 
 
+def test_classify_and_index_are_independent_of_batching(cuda, vgg_model):
+    """`batch_size` (production.py:23; 8 in cli/eval.py) bounds one forward pass of the reference; here passes are coalesced
+    up to production.ENGINE_BATCH images.  Per-crop results must not depend on the batch they ran in: labels and embeddings of
+    classify() and the gallery index are bit-identical between 5-image passes and one coalesced pass."""
+    from cvpce_amd import production, synthetic
+    enc, _ = vgg_model
+    gal = synthetic.gallery_images(23, seed=11)
+    crops = (synthetic.gallery_images(37, seed=12) + 1) / 2          # [0,1] like resize_for_classification's output
+    keep = production.ENGINE_BATCH
+    try:
+        production.ENGINE_BATCH = 1                                  # -> every pass is exactly batch_size images
+        small = production.Classifier(enc, synthetic.TensorGallery(gal), device=cuda, emb_device=cuda, batch_size=5, num_workers=0)
+        l_small, e_small = small.classify(crops.to(cuda), return_embedding=True)
+        production.ENGINE_BATCH = keep
+        big = production.Classifier(enc, synthetic.TensorGallery(gal), device=cuda, emb_device=cuda, batch_size=5, num_workers=0)
+        l_big, e_big = big.classify(crops.to(cuda), return_embedding=True)
+    finally:
+        production.ENGINE_BATCH = keep
+    assert torch.equal(small.embedding, big.embedding) and small.annotations == big.annotations
+    assert l_small == l_big and torch.equal(e_small, e_big)
+    assert len(l_big) == 37 and e_big.shape == (37, 1024)
+
+
 def test_cpu_device_fails_loudly():
     from cvpce_amd import synthetic
     from cvpce_amd.models import classification as C
