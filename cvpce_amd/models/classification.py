@@ -31,6 +31,20 @@ MAX_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 256))  # crops per ke
 # count (conv5_x: two workgroups per crop); measured on the pipeline bench, same call: 256 -> 156.4, 512 -> 158.1, 768 -> 158.6,
 # 800 -> 157.6, 400 -> 153.5, 200 -> 150.6 images/s.
 FUSED_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 768))
+FUSED_EMBED_MAX = int(_os.environ.get('CVPCE_EMBED_MAX', 960))     # largest pass the 32-bit tensor limits allow with the fused stem (conv2_x output: 960 * 128 * 128 * 128 < 2^31)
+
+
+def _passes(n, step, longest):
+    """[(start, end), ...] covering n crops in passes of `step`; a short tail is folded into the pass before it when the sum stays
+    within `longest` (1600 crops: 768 + 832 instead of 768 + 768 + 64 -- the tail pass costs 13 launches for 4 % of the work)."""
+    sizes = [step] * (n // step) + ([n % step] if n % step else [])
+    if len(sizes) >= 2 and sizes[-1] + sizes[-2] <= longest:
+        sizes[-2:] = [sizes[-1] + sizes[-2]]
+    out, s = [], 0
+    for z in sizes:
+        out.append((s, s + z))
+        s += z
+    return out
 
 
 def _vgg_features(cfg, batch_norm):
@@ -93,10 +107,11 @@ class MACVGGEngine:
         batch: crops per pass of the kernel schedule (default MAX_EMBED_BATCH; a host that runs on fewer CUs passes that
         CU count so that the persistent kernels' tile counts stay whole multiples of their grid)."""
         outs, outs_bf = [], []
-        step = batch or (FUSED_EMBED_BATCH if self.stem is not None and x.shape[1] * x.shape[2] <= INPUT_SIZE * INPUT_SIZE else MAX_EMBED_BATCH)
+        fused = batch is None and self.stem is not None and x.shape[1] * x.shape[2] <= INPUT_SIZE * INPUT_SIZE
+        step = batch or (FUSED_EMBED_BATCH if fused else MAX_EMBED_BATCH)
         plan = self.plan + [('desc', None)]            # the second descriptor: amax of the last map (classification.py:48-49)
-        for s in range(0, x.shape[0], step):
-            xb = x[s:s + step]
+        for s, e in _passes(x.shape[0], step, FUSED_EMBED_MAX if fused else step):
+            xb = x[s:e]
             desc = torch.zeros((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)   # (zeros: the fused MAC epilogue takes atomic maxima of values >= 0)
             off = 0
             if self.stem is not None:
