@@ -83,13 +83,44 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
     if (tid == 0) { s_cnt = 0; s_nsel = 0; s_eqbase = 0; s_eqtotal = 0; }
     sel[tid] = 0ull;
     __syncthreads();
-    // Every pass over the level's logits keeps UNROLL independent loads in flight per thread (a dependent-load loop spends
-    // ~0.5 us per iteration on the P3 level's 88 iterations) and evaluates the score test exactly as the oracle does.
-    constexpr int UNROLL = 8;
+    // The first R * 1024 logits of a level are read from memory ONCE: every thread keeps R keys in registers (0 = not a
+    // candidate) and the count, the four radix passes and the compaction run on them; what lies beyond (P3 of an 800 x 800
+    // image has 90 000 logits, 128 VGPRs at 1024 threads hold 56 keys per thread) is STREAMED: every pass re-reads it with
+    // UNROLL independent loads in flight per thread.  Six full passes over memory cost the P3 workgroup 6 x 11 round trips
+    // of ~2.5 us; now 11 + 5 x 4.  Both parts evaluate the score test exactly as the oracle does.
+    constexpr int UNROLL = 8, R = 56;
     const int lane = tid & 63;
+    const int nreg = n < R * 1024 ? n : R * 1024;       // logits [0, nreg) live in registers, [nreg, n) are streamed
+    unsigned keys[R];
+    // wave-aggregated histogram update: the lanes that share the first active lane's bin are counted by ONE LDS atomic (on the
+    // leading digits nearly every key of a level falls into the same two or three bins, and 64 lanes hitting one bin
+    // serialise), the others add individually
+    auto hist_add = [&](bool pred, unsigned bin) {
+        const unsigned long long act = __ballot(pred);
+        if (act) {
+            const int leader = __ffsll((long long)act) - 1;
+            const unsigned lb = (unsigned)__shfl((int)bin, leader);
+            const bool same = pred && bin == lb;
+            const unsigned long long sm = __ballot(same);
+            if (lane == leader) atomicAdd(&hist[lb], __popcll(sm));
+            if (pred && !same) atomicAdd(&hist[bin], 1);
+        }
+    };
+    auto take = [&](unsigned key, int i) {
+        const int pos = atomicAdd(&s_nsel, 1);
+        if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    };
     // count candidates above the score threshold
     int local = 0;
-    for (int base = 0; base < n; base += UNROLL * 1024) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int i = u * 1024 + tid;
+        const float l = lg[i < nreg ? i : nreg - 1];            // (clamped, not predicated: the loads stay independent)
+        const bool ok = i < nreg && sigmoidf_ref(l) > a.score_thresh;
+        keys[u] = ok ? ordered_key(l) : 0u;                     // ordered_key is 0 only for one NaN pattern, never a candidate
+        local += ok ? 1 : 0;
+    }
+    for (int base = nreg; base < n; base += UNROLL * 1024) {
         float v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) { const int i = base + u * 1024 + tid; v[u] = i < n ? lg[i] : -INFINITY; }
@@ -111,27 +142,19 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (int base = 0; base < n; base += UNROLL * 1024) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const unsigned key = keys[u];
+                hist_add(key != 0u && (key & mask) == prefix, (key >> shift) & 255u);
+            }
+            for (int base = nreg; base < n; base += UNROLL * 1024) {
                 float v[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) { const int i = base + u * 1024 + tid; v[u] = i < n ? lg[i] : -INFINITY; }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const unsigned key = ordered_key(v[u]);
-                    const bool pred = (sigmoidf_ref(v[u]) > a.score_thresh) && ((key & mask) == prefix);
-                    const unsigned bin = (key >> shift) & 255u;
-                    // wave-aggregated histogram update: the lanes that share the first active lane's bin are counted by ONE
-                    // LDS atomic (on the leading digits nearly every key of a level falls into the same two or three bins,
-                    // and 64 lanes hitting one bin serialise), the others add individually
-                    const unsigned long long act = __ballot(pred);
-                    if (act) {
-                        const int leader = __ffsll((long long)act) - 1;
-                        const unsigned lb = (unsigned)__shfl((int)bin, leader);
-                        const bool same = pred && bin == lb;
-                        const unsigned long long sm = __ballot(same);
-                        if (lane == leader) atomicAdd(&hist[lb], __popcll(sm));
-                        if (pred && !same) atomicAdd(&hist[bin], 1);
-                    }
+                    hist_add((sigmoidf_ref(v[u]) > a.score_thresh) && ((key & mask) == prefix), (key >> shift) & 255u);
                 }
             }
             __syncthreads();
@@ -157,18 +180,19 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
     if (cnt <= k || need_eq == s_eqtotal) {
         // every candidate with key >= T is taken (all ties at T fit): the order of arrival is irrelevant, the bitonic sort
         // below orders by (key, index)
-        for (int base = 0; base < n; base += UNROLL * 1024) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const unsigned key = keys[u];
+            if (key != 0u && (cnt <= k || key >= T)) take(key, u * 1024 + tid);
+        }
+        for (int base = nreg; base < n; base += UNROLL * 1024) {
             float v[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) { const int i = base + u * 1024 + tid; v[u] = i < n ? lg[i] : -INFINITY; }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int i = base + u * 1024 + tid;
                 const unsigned key = ordered_key(v[u]);
-                if ((sigmoidf_ref(v[u]) > a.score_thresh) && (cnt <= k || key >= T)) {
-                    const int pos = atomicAdd(&s_nsel, 1);
-                    if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-                }
+                if ((sigmoidf_ref(v[u]) > a.score_thresh) && (cnt <= k || key >= T)) take(key, base + u * 1024 + tid);
             }
         }
     } else {
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
                 key = ordered_key(l);
                 gt = valid && key > T; eq = valid && key == T;
             }
-            bool take = gt;
+            bool tk = gt;
             unsigned long long bal = __ballot(eq);
             int w = tid >> 6;
             int pre = __popcll(bal & ((1ull << lane) - 1ull));
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
             __syncthreads();
             int before = s_eqbase;
             for (int ww = 0; ww < w; ++ww) before += wtot[ww];
-            if (eq && before + pre < need_eq) take = true;
+            if (eq && before + pre < need_eq) tk = true;
             __syncthreads();
             if (tid == 0) {
                 int t = 0;
@@ -199,10 +223,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
                 s_eqbase += t;
             }
             __syncthreads();
-            if (take) {
-                int pos = atomicAdd(&s_nsel, 1);
-                if (pos < 1024) sel[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-            }
+            if (tk) take(key, i);
         }
     }
     __syncthreads();
