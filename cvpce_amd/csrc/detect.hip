@@ -68,6 +68,32 @@ __device__ void bitonic_sort_desc(unsigned long long* s, int n, int tid, int nth
     }
 }
 
+// merge sorted runs: s holds n / run consecutive runs of `run` keys (both powers of two), each already sorted descending; the
+// merge phases of the bitonic network (first sub-step against the mirrored partner i ^ (k - 1), so that both halves may be
+// sorted in the SAME direction) finish the sort in sum_{k = 2 run .. n} log2(k) stages instead of log2(n) (log2(n) + 1) / 2
+__device__ void merge_runs_desc(unsigned long long* s, int n, int run, int tid, int nthreads) {
+    for (int k = run << 1; k <= n; k <<= 1) {
+        for (int i = tid; i < n; i += nthreads) {
+            const int p = i ^ (k - 1);
+            if (p > i) {
+                const unsigned long long a = s[i], b = s[p];
+                if (a < b) { s[i] = b; s[p] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += nthreads) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = s[i], b = s[p];
+                    if (a < b) { s[i] = b; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void decode_topk_kernel(DecodeArgs a) {
     __shared__ unsigned long long sel[1024];
     __shared__ int hist[256];
@@ -285,16 +311,18 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(NmsArgs a) {
     }
     __syncthreads();
     const int T = offs[a.L];
-    int npow = 1;
-    while (npow < T) npow <<= 1;
-    if (npow < 2) npow = 2;
+    // Each level's candidates arrive sorted (decode_topk_kernel: logit descending, then lower anchor index): level l is laid
+    // into the 1024-key segment l, zero-padded, and the segments are MERGED (36 network stages for 8 segments) instead of
+    // sorted from scratch (91).  Low word = ~(segment position): ties resolve to the lower level, then the lower rank, which
+    // is the order of the concatenated candidate list.
+    int npow = 1024;
+    while (npow < a.L * 1024) npow <<= 1;
     float mx = -INFINITY;
     for (int i = tid; i < npow; i += 1024) {
         unsigned long long kv = 0ull;
-        if (i < T) {
-            int l = 0;
-            while (l + 1 < a.L && i >= offs[l + 1]) ++l;
-            const int src = l * a.topk + (i - offs[l]);
+        const int l = i >> 10, r = i & 1023;
+        if (l < a.L && r < offs[l + 1] - offs[l]) {
+            const int src = l * a.topk + r;
             kv = ((unsigned long long)ordered_key(a.cand_logits[(size_t)img * slot + src]) << 32) |
                  (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
             const float4 b = *reinterpret_cast<const float4*>(a.cand_boxes + ((size_t)img * slot + src) * 4);
@@ -308,13 +336,11 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(NmsArgs a) {
     __syncthreads();
     mx = s_max[0];
     for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_max[w]);
-    bitonic_sort_desc(keys, npow, tid, 1024);
+    merge_runs_desc(keys, npow, 1024, tid, 1024);
     if (tid == 0) a.s_total[img] = T;
     for (int r = tid; r < T; r += 1024) {
         const int i = (int)(0xFFFFFFFFu - (unsigned)(keys[r] & 0xFFFFFFFFull));
-        int l = 0;
-        while (l + 1 < a.L && i >= offs[l + 1]) ++l;
-        const size_t src = (size_t)img * slot + l * a.topk + (i - offs[l]);
+        const size_t src = (size_t)img * slot + (i >> 10) * a.topk + (i & 1023);
         const size_t dst = (size_t)img * a.Tmax + r;
         *reinterpret_cast<float4*>(a.s_boxes + dst * 4) = *reinterpret_cast<const float4*>(a.cand_boxes + src * 4);
         a.s_scores[dst] = a.cand_scores[src];
