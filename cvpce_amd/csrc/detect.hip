@@ -412,10 +412,18 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(NmsArgs a) {
     __syncthreads();
     const unsigned long long* M = a.mask + (size_t)img * a.Tmax * a.words;
     const int w = tid & 127, g = tid >> 7;                // word owned in the propagation step, group of 8 chunk rows
+    // (the diagonal word of chunk b + 1 is fetched while chunk b is resolved and propagated: its L2 latency leaves the chain)
+    unsigned long long diag_next = (wave == 0 && lane < T) ? M[(size_t)lane * a.words] : 0ull;
     for (int b = 0; b < nw; ++b) {
         if (wave == 0) {
             const int row = b * 64 + lane;
-            const unsigned long long diag = (row < T) ? M[(size_t)row * a.words + b] : 0ull;
+            const unsigned long long diag = diag_next;
+            {
+                int rn = row + 64;
+                rn = rn < T ? rn : T - 1;
+                const unsigned long long nx = M[(size_t)rn * a.words + (b + 1 < nw ? b + 1 : b)];
+                diag_next = (row + 64 < T) ? nx : 0ull;
+            }
             const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
             const int rows_here = (T - b * 64) < 64 ? (T - b * 64) : 64;
             const unsigned long long valid = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
