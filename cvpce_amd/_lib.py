@@ -33,6 +33,7 @@ SIGNATURES = {
     'cvpce_conv1x1_nhwc_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 14 + [_vp]),
     'cvpce_vgg_stem_fused': (c_int, [_vp, c_int, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp]),
     'cvpce_gln_stem_fused': (c_int, [_vp, _vp, _fp, _vp, c_int, c_int, c_int, _vp]),
+    'cvpce_atlas_copy': (c_int, [POINTER(_vp), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int, c_int, _vp, c_int, c_int, c_int, c_int, _vp]),
     'cvpce_conv3x3_halo': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_conv3x3_halo_mac': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 8 + [_vp]),
     'cvpce_conv3x3_halo_wide': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),

@@ -146,3 +146,57 @@ extern "C" int cvpce_set_persistent_workgroups(int n) {
     g_cvpce_persistent_wgs = n;
     return CVPCE_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// Level atlas <-> per-level tensors in ONE launch (the detector's head towers run on an atlas of the five pyramid levels;
+// five slice copies in, ten out were fifteen launches on the critical chain).  Unit = one 4- or 16-byte word of a pixel.
+struct AtlasCopyArgs {
+    void* level[8];                 // [N][h][w][bytes_per_pixel]
+    int h[8], w[8], oy[8], ox[8], first[9];   // first[l] = pixels of levels < l (per image)
+    void* atlas;                    // [N][hc][wc][bytes_per_pixel]
+    int L, N, hc, wc, bpp, to_atlas;
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void atlas_copy_kernel(AtlasCopyArgs a) {
+    const int upp = a.bpp / (int)sizeof(V);                       // units per pixel
+    const long long total = (long long)a.N * a.first[a.L] * upp;
+    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
+        const long long p = u / upp;
+        const int within = (int)(u - p * upp);
+        const int n = (int)(p / a.first[a.L]);
+        const int q = (int)(p - (long long)n * a.first[a.L]);
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) l += (i < a.L && q >= a.first[i]) ? 1 : 0;
+        const int r = q - a.first[l], y = r / a.w[l], x = r - y * a.w[l];
+        V* lv = reinterpret_cast<V*>(a.level[l]) + ((size_t)(n * a.h[l] + y) * a.w[l] + x) * upp + within;
+        V* at = reinterpret_cast<V*>(a.atlas) + ((size_t)(n * a.hc + a.oy[l] + y) * a.wc + a.ox[l] + x) * upp + within;
+        if (a.to_atlas) *at = *lv; else *lv = *at;
+    }
+}
+
+extern "C" int cvpce_atlas_copy(void* const* levels, const int* h, const int* w, const int* oy, const int* ox, int L, int N,
+                                void* atlas, int hc, int wc, int bytes_per_pixel, int to_atlas, void* stream) {
+    if (N <= 0 || L <= 0) return CVPCE_OK;
+    if (!levels || !h || !w || !oy || !ox || !atlas || L > 8 || hc <= 0 || wc <= 0 || bytes_per_pixel <= 0 || bytes_per_pixel % 4) return CVPCE_ERR_ARG;
+    AtlasCopyArgs a;
+    a.first[0] = 0;
+    for (int l = 0; l < 8; ++l) {
+        const bool on = l < L;
+        a.level[l] = on ? levels[l] : nullptr;
+        a.h[l] = on ? h[l] : 0; a.w[l] = on ? w[l] : 1; a.oy[l] = on ? oy[l] : 0; a.ox[l] = on ? ox[l] : 0;
+        if (on && (!levels[l] || h[l] <= 0 || w[l] <= 0 || oy[l] < 0 || ox[l] < 0 || oy[l] + h[l] > hc || ox[l] + w[l] > wc)) return CVPCE_ERR_ARG;
+        a.first[l + 1] = a.first[l] + (on ? h[l] * w[l] : 0);
+    }
+    a.atlas = atlas; a.L = L; a.N = N; a.hc = hc; a.wc = wc; a.bpp = bytes_per_pixel; a.to_atlas = to_atlas;
+    const bool wide = bytes_per_pixel % 16 == 0;
+    const long long total = (long long)N * a.first[L] * (bytes_per_pixel / (wide ? 16 : 4));
+    if (total <= 0) return CVPCE_OK;
+    const long long want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+    if (wide) hipLaunchKernelGGL(atlas_copy_kernel<uint4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(atlas_copy_kernel<unsigned>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return cvpce_check_launch();
+}

@@ -35,6 +35,7 @@ N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP 
 USE_DETECT_GRAPH = True   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
 MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image)
 USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
+USE_ATLAS_COPY = os.environ.get('CVPCE_ATLAS_COPY', '1') != '0'       # levels <-> atlas in one launch each way (15 slice copies otherwise)
 USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
 
 
@@ -415,8 +416,11 @@ class GLNEngine:
             bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=torch.bfloat16, device=self.device) for _ in range(5)]
         atlas, cls_a, cls_b, reg_a, reg_b = bufs[bkey]
         self._keep(bufs[bkey])
-        for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
-            atlas[:, oy:oy + h, ox:ox + w] = f
+        if USE_ATLAS_COPY:
+            ops.atlas_pack(feats, atlas, offs)               # the five levels into the canvas, one launch
+        else:
+            for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
+                atlas[:, oy:oy + h, ox:ox + w] = f
 
         def chain(tower, final, ping, pong):
             t = atlas
@@ -424,6 +428,8 @@ class GLNEngine:
                 t = ops.conv3x3_atlas(t, pc, mask, act=1, tile_map=tile_map, out=ping, mask_pixels=npix)
                 ping, pong = pong, ping
             o = ops.conv2d(t, final, out_f32=True)           # gap pixels hold junk here; they are never read
+            if USE_ATLAS_COPY:
+                return ops.atlas_unpack(o, shapes, offs)
             return [o[:, oy:oy + h, ox:ox + w].contiguous() for (h, w), (oy, ox) in zip(shapes, offs)]
 
         main = torch.cuda.current_stream()

@@ -282,6 +282,23 @@ def conv3x3_atlas(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None)
     return out
 
 
+def atlas_pack(levels, atlas, offs):
+    """levels[l] (N,h,w,C) -> atlas[:, oy:oy+h, ox:ox+w] for every level, one launch."""
+    _need_cuda(atlas, *levels)
+    assert atlas.is_contiguous()
+    T.atlas_pack(list(levels), atlas, [int(o[0]) for o in offs], [int(o[1]) for o in offs])
+
+
+def atlas_unpack(atlas, shapes, offs):
+    """-> [atlas[:, oy:oy+h, ox:ox+w].contiguous() for every level], one launch."""
+    _need_cuda(atlas)
+    assert atlas.is_contiguous()
+    n, _, _, c = atlas.shape
+    levels = [torch.empty((n, h, w, c), dtype=atlas.dtype, device=atlas.device) for (h, w) in shapes]
+    T.atlas_unpack(atlas, levels, [int(o[0]) for o in offs], [int(o[1]) for o in offs])
+    return levels
+
+
 def vgg_stem(x, ps):
     """x: (N,H,W,4|8) bf16 normalised input -> (N,H/2,W/2,64) bf16 = pool(relu(conv(relu(conv(x)))))."""
     _need_cuda(x)

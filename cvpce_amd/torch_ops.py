@@ -150,6 +150,28 @@ def _detect_postprocess(logits, regs, gh, gw, sh, sw, base_anchors, image_hw, ra
                                        _p(conf), _stream()), 'cvpce_detect_postprocess')
 
 
+def _atlas_copy(levels, atlas, oy, ox, to_atlas):
+    L = len(levels)
+    n, hc, wc, c = atlas.shape
+    lp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels])
+    ci = lambda v: (ctypes.c_int * L)(*[int(x) for x in v])
+    for t in levels:
+        if t.dtype != atlas.dtype or t.shape[0] != n or t.shape[3] != c or not t.is_contiguous():
+            raise RuntimeError('atlas_copy: levels must be contiguous (N,h,w,C) tensors of the atlas dtype / batch / channels')
+    check(lib.cvpce_atlas_copy(lp, ci([t.shape[1] for t in levels]), ci([t.shape[2] for t in levels]), ci(oy), ci(ox), L, n, _p(atlas),
+                               hc, wc, c * atlas.element_size(), int(to_atlas), _stream()), 'cvpce_atlas_copy')
+
+
+@_op('atlas_pack(Tensor[] levels, Tensor(a!) atlas, int[] oy, int[] ox) -> ()')
+def _atlas_pack(levels, atlas, oy, ox):
+    _atlas_copy(levels, atlas, oy, ox, True)
+
+
+@_op('atlas_unpack(Tensor atlas, Tensor(a!)[] levels, int[] oy, int[] ox) -> ()')
+def _atlas_unpack(atlas, levels, oy, ox):
+    _atlas_copy(levels, atlas, oy, ox, False)
+
+
 @_op('row_norms(Tensor x, Tensor(a!) out, float eps) -> ()')
 def _row_norms(x, out, eps):
     check(lib.cvpce_row_norms(_p(x), _p(out), x.shape[0], x.shape[1], int(x.dtype == torch.float32), eps, _stream()), 'row_norms')

@@ -114,6 +114,13 @@ int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream);
 /* x.amax(dim=(-2,-1)) -> out[n*out_stride + out_off + c]  (classification.py:46-49) */
 int cvpce_global_max_nhwc_bf16(const void* in, float* out, int N, int HW, int C, int out_stride, int out_off,
                                void* stream);
+/* Level atlas <-> per-level tensors in one launch: the RetinaNet head (torchvision RetinaNetHead loops over the pyramid levels
+ * with shared weights; reached from cvpce/models/proposals.py:166) runs on ONE zero-separated atlas of the L <= 8 levels.
+ * levels[l]: [N][h[l]][w[l]][bytes_per_pixel]; atlas: [N][hc][wc][bytes_per_pixel] with level l at rows oy[l].., columns
+ * ox[l]..; to_atlas = 1 copies the levels in, 0 copies them out.  bytes_per_pixel % 4 == 0.  Host arrays are read at the call. */
+int cvpce_atlas_copy(void* const* levels, const int* h, const int* w, const int* oy, const int* ox, int L, int N,
+                     void* atlas, int hc, int wc, int bytes_per_pixel, int to_atlas, void* stream);
+
 /* desc / norm(desc).clamp(min=eps) (classification.py:51); out_bf16 optional */
 int cvpce_l2_normalize_f32(const float* in, float* out, void* out_bf16, int B, int D, float eps, void* stream);
 

@@ -451,6 +451,29 @@ def test_gln_stem_channel3_ignored(cuda):
     assert torch.equal(ops.gln_stem(x.to(cuda), ps), ops.gln_stem(clean.to(cuda), ps))
 
 
+@pytest.mark.parametrize('dtype,c', [(torch.bfloat16, 256), (torch.float32, 9), (torch.float32, 36), (torch.bfloat16, 8)])
+def test_atlas_pack_unpack(cuda, dtype, c):
+    """One-launch level atlas <-> per-level copies against plain slicing (the layout GLNEngine.atlas_layout produces)."""
+    from cvpce_amd import ops
+    from cvpce_amd.models.proposals import GLNEngine
+    shapes = [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)]
+    hc, wc, offs = GLNEngine.atlas_layout(shapes)
+    g = torch.Generator().manual_seed(c)
+    levels = [torch.randn(3, h, w, c, generator=g).to(dtype).to(cuda) for h, w in shapes]
+    atlas = torch.zeros(3, hc, wc, c, dtype=dtype, device=cuda)
+    ops.atlas_pack(levels, atlas, offs)
+    want = torch.zeros_like(atlas)
+    for f, (h, w), (oy, ox) in zip(levels, shapes, offs):
+        want[:, oy:oy + h, ox:ox + w] = f
+    assert torch.equal(atlas, want)                               # and the gaps are untouched (still zero)
+    junk = torch.randn(3, hc, wc, c, generator=g).to(dtype).to(cuda)
+    back = ops.atlas_unpack(junk, shapes, offs)
+    for t, (h, w), (oy, ox) in zip(back, shapes, offs):
+        assert t.is_contiguous() and torch.equal(t, junk[:, oy:oy + h, ox:ox + w])
+    with pytest.raises(RuntimeError):
+        ops.atlas_pack(levels, atlas, [(o[0] + 60, o[1]) for o in offs])      # a level would leave the canvas
+
+
 HALO_CASES = [  # n, cin, h, w, cout, pool
     (4, 128, 128, 128, 128, True),     # VGG conv2_2 shape (TC = 128, pooled)
     (16, 128, 64, 64, 256, False),     # conv3_1
