@@ -1,0 +1,13 @@
+"""dev tool: one step of a rocprofv3 --kernel-trace as a timeline (start offset, duration, gap since the latest end so far, kernel)."""
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
+per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+marks = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('gln_transform_kernel')]
+s, e = marks[-2 * per_step], marks[-per_step]
+t0 = int(rows[s]['Start_Timestamp']); latest = t0
+for r in rows[s:e]:
+    a, b = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    gap = (a - latest) / 1e3
+    print(f'{(a - t0) / 1e3:8.1f} us  {(b - a) / 1e3:7.1f} us  gap {gap:6.1f}  {r["Kernel_Name"][:70]}')
+    latest = max(latest, b)
