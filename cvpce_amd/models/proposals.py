@@ -553,7 +553,7 @@ class GLNEngine:
             self.transform(images, out=entry['static_in'])
         entry['graph'].replay()
         # results leave the graph's private memory: a later replay must not overwrite what the caller still holds
-        return tuple(t.clone() for t in entry['static_out'])
+        return ops.clone_views(entry['static_out'])
 
     def _detect_tail(self, batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates):
         c2, c3, c4, c5 = self.body(batch)

@@ -113,6 +113,7 @@ PROFILE = None   # set to a ConvProfile() to record
 
 CONV1X1_ANY_SHAPE = bool(int(_os.environ.get('CVPCE_CONV1X1_ANY', '0')))   # test switch: every eligible 1x1 conv through the pointwise kernel
 CONV1X1_MAX_CIN = int(_os.environ.get('CVPCE_CONV1X1_MAX_CIN', '256'))   # expansion convs up to this Cin (512 -- the 25 x 25 stage of ResNet-50 -- measured slower: 3.32 -> 3.36 ms detector only)
+ONE_OUTPUT_BLOCK = _os.environ.get('CVPCE_ONE_OUTPUT_BLOCK', '1') != '0'   # detect_postprocess outputs as views of one block (A/B switch)
 USE_CONV1X1 = True           # 1x1 convs with Cin, Cout % 64 == 0 through the LDS-free pointwise GEMM kernel (A/B switch)
 HALO_RAGGED = bool(int(_os.environ.get('CVPCE_HALO_RAGGED', '0')))          # test switch: also send small maps and maps that 16x16 tiles do not cover exactly through the halo kernel
 USE_HALO_3X3 = True          # A/B switch: 3x3 s1 layers with Cin % 64 == 0 through the halo-patch kernel
@@ -411,17 +412,42 @@ def detect_postprocess(logits, regs, grids, strides, base_anchors, image_hw, rat
     dev = logits[0].device
     ws_bytes = lib.cvpce_detect_workspace_bytes(n, L, topk)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    boxes = torch.zeros((n, detections_per_img, 4), dtype=torch.float32, device=dev)
-    scores = torch.zeros((n, detections_per_img), dtype=torch.float32, device=dev)
-    labels = torch.zeros((n, detections_per_img), dtype=torch.int64, device=dev)
-    count = torch.zeros((n,), dtype=torch.int32, device=dev)
-    conf = torch.zeros((n,), dtype=torch.int32, device=dev)
+    nd = n * detections_per_img
+    if ONE_OUTPUT_BLOCK:
+        # the five zero-padded outputs are views of ONE zero-filled block: one fill launch on the chain instead of five, and a
+        # caller that has to copy the results out of a captured graph's memory copies one block (clone_views)
+        zero = torch.zeros(nd * 28 + n * 8, dtype=torch.uint8, device=dev)
+        labels = zero[:nd * 8].view(torch.int64).view(n, detections_per_img)
+        boxes = zero[nd * 8:nd * 24].view(torch.float32).view(n, detections_per_img, 4)
+        scores = zero[nd * 24:nd * 28].view(torch.float32).view(n, detections_per_img)
+        count = zero[nd * 28:nd * 28 + n * 4].view(torch.int32)
+        conf = zero[nd * 28 + n * 4:].view(torch.int32)
+    else:
+        boxes = torch.zeros((n, detections_per_img, 4), dtype=torch.float32, device=dev)
+        scores = torch.zeros((n, detections_per_img), dtype=torch.float32, device=dev)
+        labels = torch.zeros((n, detections_per_img), dtype=torch.int64, device=dev)
+        count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        conf = torch.zeros((n,), dtype=torch.int32, device=dev)
     for t in list(logits) + list(regs):
         assert t.dtype == torch.float32 and t.is_contiguous()
     T.detect_postprocess(list(logits), list(regs), [int(g[0]) for g in grids], [int(g[1]) for g in grids], [int(s[0]) for s in strides],
                          [int(s[1]) for s in strides], base_anchors, image_hw, ratios, num_anchors, num_classes, topk, float(score_thresh),
                          float(nms_thresh), float(xform_clip), detections_per_img, float(conf_thresh), ws, boxes, scores, labels, count, conf)
     return boxes, scores, labels, count, conf
+
+
+def clone_views(tensors):
+    """tuple of clones of `tensors`; tensors that share one storage (views of one block) are cloned with ONE copy of it.
+    (Grouped by storage, not by `_base`: a dtype-changing `.view()` starts a new base chain on the same storage.)"""
+    blocks, out = {}, []
+    for t in tensors:
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        if key not in blocks:
+            whole = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st, 0, (st.nbytes(),), (1,))
+            blocks[key] = whole.clone().untyped_storage()
+        out.append(torch.empty(0, dtype=t.dtype, device=t.device).set_(blocks[key], t.storage_offset(), t.size(), t.stride()))
+    return tuple(out)
 
 
 # ---------------------------------------------------------------------------
