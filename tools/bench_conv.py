@@ -19,6 +19,12 @@ LAYERS = {
     'res_c2_1x1': (8, 64, 200, 200, 256, 1, 1, 0, False),
     'res_c3_3x3': (8, 128, 100, 100, 128, 3, 1, 1, False),
     'head_p3': (8, 256, 100, 100, 256, 3, 1, 1, False),
+    # small-M detector layers (4 images): latency-bound launches of the register-staged kernel
+    'l3_c1': (4, 1024, 50, 50, 256, 1, 1, 0, False),
+    'l4_c1': (4, 2048, 25, 25, 512, 1, 1, 0, False),
+    'l4_c2': (4, 512, 25, 25, 512, 3, 1, 1, False),
+    'l4_c3': (4, 512, 25, 25, 2048, 1, 1, 0, False),
+    'l4_c3_res': (4, 512, 25, 25, 2048, 1, 1, 0, False),
 }
 
 ap = argparse.ArgumentParser()
@@ -51,13 +57,17 @@ for name in args.layers.split(','):
     x = (torch.randn(n, h, w, pc.cin_pad, generator=g)).to(torch.bfloat16).to(dev)
     if args.relu_input:
         x = torch.relu(x)
+    res = None
+    if name.endswith('_res'):
+        ho, wo = pc.out_hw(h, w)
+        res = torch.randn(n, ho, wo, cout, generator=g).to(torch.bfloat16).to(dev)
     for _ in range(2):
-        y = ops.conv2d(x, pc, act=1, pool=pool)
+        y = ops.conv2d(x, pc, act=1, pool=pool, residual=res)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.iters):
-        y = ops.conv2d(x, pc, act=1, pool=pool)
+        y = ops.conv2d(x, pc, act=1, pool=pool, residual=res)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
