@@ -56,6 +56,13 @@ SIGNATURES = {
     'cvpce_probe_mfma_bf16': (c_int, [c_int, c_int, _vp, _fp, c_int, _vp]),
     'cvpce_match_topk': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _vp, c_size_t, _vp, _fp, _vp]),
 }
+# fp16 twins of the detector's kernels (the opt-in accuracy mode): same argument lists as the functions they are named after
+for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16'),
+                     ('cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16'), ('cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16'),
+                     ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
+                     ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'),
+                     ('cvpce_gln_transform', 'cvpce_gln_transform_f16')):
+    SIGNATURES[_twin] = SIGNATURES[_base]
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)   # AttributeError here = header/library mismatch: fail loudly

@@ -10,6 +10,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define CVPCE_OK 0
 #define CVPCE_ERR_ARG 1
@@ -22,6 +25,43 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }  //
 
 // four floats -> four bf16 with two v_cvt_pk_bf16_f32 (element-wise casts compile to one conversion + a v_perm each)
 __device__ __forceinline__ bf16x4 f32x4_to_bf16x4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Element type of the 16-bit activations and weights.  The kernels move 16-bit data as opaque 128- / 64-bit words (bf16x8 /
+// bf16x4 registers, LDS-DMA pieces, buffer loads, ds_read_b128): the element type matters only where values are MULTIPLIED
+// (the MFMA instruction) and where they are CONVERTED (epilogue stores, residual reads).  Every convolution kernel of the
+// detector is a template over one of these two policies; both run the matrix pipe at the same rate
+// (v_mfma_f32_16x16x32_{bf16,f16}: 8 passes, v_mfma_f32_32x32x16_{bf16,f16}: 16 passes).
+//   ElemBF16  the default storage type (BASELINE configs name bf16): 8 exponent / 7 mantissa bits
+//   ElemF16   the detector's opt-in accuracy mode (`gln(..., precision='fp16')`): 5 / 10 bits -- 8x finer rounding of
+//             weights and activations (head-logit error 1.75 % -> 0.24 % of the logit spread, profiles/r03_numerics_study.json);
+//             stores saturate at +-65504 instead of overflowing to infinity.
+// `bf16x8` / `bf16x4` / `bf16_t` in a kernel's registers are bit containers under ElemF16.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ElemBF16 {
+    static constexpr bool kF16 = false;
+    static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ bf16x4 pack4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+    static __device__ __forceinline__ bf16_t narrow(float v) { return (bf16_t)v; }
+    static __device__ __forceinline__ float widen(bf16_t raw) { return (float)raw; }
+};
+struct ElemF16 {
+    static constexpr bool kF16 = true;
+    static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ bf16x4 pack4(f32x4 v) {   // v_med3_f32 x4 + v_cvt_pk_f16_f32 x2 (RNE)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+        return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, f16x4));
+    }
+    static __device__ __forceinline__ bf16_t narrow(float v) { return __builtin_bit_cast(bf16_t, (f16_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f)); }
+    static __device__ __forceinline__ float widen(bf16_t raw) { return (float)__builtin_bit_cast(f16_t, raw); }
+};
 
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD
 // (round-robin dispatch), so give each XCD label a contiguous chunk of the

@@ -22,6 +22,7 @@ struct C1Args {
     unsigned in_bytes, wgt_bytes;
 };
 
+template <typename E>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
 #define C1_MFMA(BUF)                                                                                           \
     _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)                                                        \
         _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                                    \
-            acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[BUF][mt_], B[BUF][nt_], acc[mt_][nt_], 0, 0, 0);
+            acc[mt_][nt_] = E::mfma16(A[BUF][mt_], B[BUF][nt_], acc[mt_][nt_]);
 
     const int ks = a.K_pad >> 5;          // K-steps of 32 (even: K_pad % 64 == 0)
     C1_LOAD(0, 0)
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
             const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(a.res + rp * a.Cout + co);
             const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(a.res + rp * a.Cout + co + 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[j] += bf16_to_f32(r0[j]); v[8 + j] += bf16_to_f32(r1[j]); }
+            for (int j = 0; j < 8; ++j) { v[j] += E::widen(r0[j]); v[8 + j] += E::widen(r1[j]); }
         }
         if (a.relu) {
 #pragma unroll
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
         unsigned pk[8];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const uint2 u = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}));
+            const uint2 u = __builtin_bit_cast(uint2, E::pack4(f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}));
             pk[2 * g] = u.x; pk[2 * g + 1] = u.y;
         }
         bf16_t* dst = a.out + (size_t)m * a.Cout + co;
@@ -117,9 +118,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
     }
 }
 
-extern "C" int cvpce_conv1x1_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N,
-                                       int H, int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad,
-                                       int relu, int res_mode, int Hr, int Wr, void* stream) {
+template <typename E>
+static int conv1x1_dispatch(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N,
+                            int H, int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad,
+                            int relu, int res_mode, int Hr, int Wr, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (H <= 0 || W <= 0 || stride < 1 || Cin <= 0 || Cin % 64 != 0 || K_pad != Cin || Cout <= 0 || Cout % 64 != 0) return CVPCE_ERR_ARG;
@@ -139,6 +141,17 @@ extern "C" int cvpce_conv1x1_nhwc_bf16(const void* in, const void* wgt, const fl
     a.ntiles = (int)nt;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
-    hipLaunchKernelGGL(conv1x1_kernel, dim3((a.ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv1x1_kernel<E>, dim3((a.ntiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return cvpce_check_launch();
+}
+
+extern "C" int cvpce_conv1x1_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N,
+                                       int H, int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad,
+                                       int relu, int res_mode, int Hr, int Wr, void* stream) {
+    return conv1x1_dispatch<ElemBF16>(in, wgt, bias, res, out, N, H, W, Cin, Cout, stride, Ho, Wo, K_pad, Cout_pad, relu, res_mode, Hr, Wr, stream);
+}
+extern "C" int cvpce_conv1x1_nhwc_f16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N,
+                                      int H, int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad,
+                                      int relu, int res_mode, int Hr, int Wr, void* stream) {
+    return conv1x1_dispatch<ElemF16>(in, wgt, bias, res, out, N, H, W, Cin, Cout, stride, Ho, Wo, K_pad, Cout_pad, relu, res_mode, Hr, Wr, stream);
 }

@@ -58,7 +58,7 @@ struct Halo2Args {
     unsigned in_bytes, wgt_bytes;
 };
 
-template <bool POOL, bool GMAX>
+template <typename E, bool POOL, bool GMAX>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     constexpr int TC = 256, NB = 16;
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
                 _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                            \
-                    acc[mt_][(P) - kh_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(T) & 1][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_], 0, 0, 0); \
+                    acc[mt_][(P) - kh_] = E::mfma16(af[(T) & 1][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_]); \
             }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                     unsigned* g = reinterpret_cast<unsigned*>(a.gmax) + (size_t)n * a.gmax_stride + a.gmax_off + co;
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (co + j < a.Cout) atomicMax(g + j, __float_as_uint((float)f32_to_bf16(__uint_as_float(m[j]))));
+                        if (co + j < a.Cout) atomicMax(g + j, __float_as_uint(E::widen(E::narrow(__uint_as_float(m[j])))));
                 }
             }
             if (GMAX && a.out == nullptr) {
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                             }
                         }
                     if (lane_ok && oy < (a.H >> 1) && co < a.Cout && !(CVPCE_DBG & 16)) {
-                        const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[0], r[1], r[2], r[3]}));
-                        const uint2 h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[4], r[5], r[6], r[7]}));
+                        const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[0], r[1], r[2], r[3]}));
+                        const uint2 h2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
                 }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                         for (int j = 0; j < 4; ++j) { r0[j] = relu_bits(r0[j]); r1[j] = relu_bits(r1[j]); }
                     }
                     if (store_lane && co < a.Cout && !(CVPCE_DBG & 16)) {
-                        const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r0)), h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r1));
+                        const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(r0)), h2 = __builtin_bit_cast(uint2, E::pack4(r1));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = keep ? u32x4{l2.x, l2.y, h2.x, h2.y} : u32x4{0u, 0u, 0u, 0u};
                     }
                 }
@@ -414,22 +414,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #undef G2_LOAD_A
 }
 
-template <bool POOL, bool GMAX>
+template <typename E, bool POOL, bool GMAX>
 static int launch_halo2(Halo2Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 255) / 256;
     a.ntiles = a.ptiles * a.ctiles;
     const int smem = 3 * G2_A_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<POOL, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<E, POOL, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
-    hipLaunchKernelGGL((conv3x3_halo2_kernel<POOL, GMAX>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
+template <typename E>
 static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, const int* tile_map,
                           int n_map, void* out, float* gmax,
                           int gmax_stride, int gmax_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
@@ -448,7 +449,7 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     // (CVPCE_DBG & 256, dev A/B only: also route every map that 32-pixel-wide tiles cover exactly to the wide-tile kernel --
     //  measured and not adopted, profiles/r02_ablation_halo2.md)
     if ((Cout <= 128 || ((CVPCE_DBG & 256) && !gmax && W % 32 == 0 && H % 16 == 0)) && !mask)
-        return cvpce_conv3x3_halo_wide(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+        return (E::kF16 ? cvpce_conv3x3_halo_wide_f16 : cvpce_conv3x3_halo_wide)(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
     Halo2Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = mask; a.out = (bf16_t*)out;
     a.gmax = gmax; a.gmax_stride = gmax_stride; a.gmax_off = gmax_off;
@@ -461,25 +462,38 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     a.ctiles = a.ntiles = 0;
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (gmax) return fuse_pool2 ? launch_halo2<true, true>(a, s) : launch_halo2<false, true>(a, s);
-    return fuse_pool2 ? launch_halo2<true, false>(a, s) : launch_halo2<false, false>(a, s);
+    if (gmax) return fuse_pool2 ? launch_halo2<E, true, true>(a, s) : launch_halo2<E, false, true>(a, s);
+    return fuse_pool2 ? launch_halo2<E, true, false>(a, s) : launch_halo2<E, false, false>(a, s);
 }
 
 extern "C" int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
                                   int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
-    return halo2_dispatch(in, wgt, bias, nullptr, nullptr, 0, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+    return halo2_dispatch<ElemBF16>(in, wgt, bias, nullptr, nullptr, 0, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
 }
 
 extern "C" int cvpce_conv3x3_halo_mac(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
                                       int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad,
                                       int fuse_pool2, void* stream) {
     if (!mac) return CVPCE_ERR_ARG;
-    return halo2_dispatch(in, wgt, bias, nullptr, nullptr, 0, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, 1, fuse_pool2, stream);
+    return halo2_dispatch<ElemBF16>(in, wgt, bias, nullptr, nullptr, 0, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, 1, fuse_pool2, stream);
 }
 
 extern "C" int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
                                          const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout,
                                          int K_pad, int Cout_pad, int relu, void* stream) {
     if (!mask) return CVPCE_ERR_ARG;
-    return halo2_dispatch(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
+    return halo2_dispatch<ElemBF16>(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
+}
+
+// fp16 twins (the detector's accuracy mode; same contracts, element type fp16)
+extern "C" int cvpce_conv3x3_halo_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                                      int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+    return halo2_dispatch<ElemF16>(in, wgt, bias, nullptr, nullptr, 0, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+}
+
+extern "C" int cvpce_conv3x3_halo_masked_f16(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                             const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout,
+                                             int K_pad, int Cout_pad, int relu, void* stream) {
+    if (!mask) return CVPCE_ERR_ARG;
+    return halo2_dispatch<ElemF16>(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
 }

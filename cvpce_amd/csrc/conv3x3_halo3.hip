@@ -44,21 +44,25 @@ struct Halo3Args {
 
 // diagnostic build only (tools/ablate.sh conv3x3_halo3 128; tools/dev/halo3_stamps.py): s_memtime ticks two waves of one workgroup
 // spend in [weights wait at the end of a step, hand-off vmcnt, hand-off barrier, epilogue, whole loop]; [5] = timed steps
+#if CVPCE_DBG & 128
 __device__ unsigned long long cvpce_halo3_stamps[2][6];
 extern "C" int cvpce_debug_halo3_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cvpce_halo3_stamps), sizeof(cvpce_halo3_stamps)) == hipSuccess ? 0 : 2;
 }
-#if CVPCE_DBG & 128
 #define G3_TIC() const unsigned long long tic_ = __builtin_amdgcn_s_memtime();
 #define G3_TOC(I) st_[I] += __builtin_amdgcn_s_memtime() - tic_;
+#define G3_STAMP_STEP() { G3_TIC() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G3_TOC(0) st_[5] += 1; }
 #else
 #define G3_TIC()
 #define G3_TOC(I)
+#define G3_STAMP_STEP()
 #endif
 
-template <bool POOL>
+template <typename E, bool POOL>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
+#if CVPCE_DBG & 128
     unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+#endif
     constexpr int TC = 128, NB = 16, NG = 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
                 _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                            \
-                    acc[mt_][(P) - kh_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(T) & 1][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_], 0, 0, 0); \
+                    acc[mt_][(P) - kh_] = E::mfma16(af[(T) & 1][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_]); \
             }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         G3_SET_E((T) + 1, bufb)                                                                                \
         G3_READ((T) + 1, 0) G3_ROW(T, 16)                                                                      \
         G3_READ((T) + 1, 1) G3_ROW(T, 17)                                                                      \
-        if constexpr (CVPCE_DBG & 128) { G3_TIC() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); G3_TOC(0) st_[5] += 1; } \
+        G3_STAMP_STEP()                                                                                        \
     }
     // last step of a sub-chunk (T = 2 or 5) with the hand-off.  After the last sub-chunk the barrier, the reads and the
     // weight loads still run, on valid but unused data, so that the loop body has one shape.
@@ -309,8 +313,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                             }
                         }
                     if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
-                        const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[0], r[1], r[2], r[3]}));
-                        const uint2 h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(f32x4{r[4], r[5], r[6], r[7]}));
+                        const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[0], r[1], r[2], r[3]}));
+                        const uint2 h2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
                 }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                         for (int j = 0; j < 4; ++j) { r0[j] = relu_bits(r0[j]); r1[j] = relu_bits(r1[j]); }
                     }
                     if (store_lane && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
-                        const uint2 l2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r0)), h2 = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r1));
+                        const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(r0)), h2 = __builtin_bit_cast(uint2, E::pack4(r1));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
                 }
@@ -364,24 +368,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #undef G3_LOAD_A
 }
 
-template <bool POOL>
+template <typename E, bool POOL>
 static int launch_halo3(Halo3Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 127) / 128;
     a.ntiles = a.ptiles * a.ctiles;
     const int smem = 3 * G3_A_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<E, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
-    hipLaunchKernelGGL((conv3x3_halo3_kernel<POOL>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<E, POOL>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
-extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
-                                       int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+template <typename E>
+static int halo3_dispatch(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                          int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
@@ -398,5 +403,14 @@ extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const fl
     a.ctiles = a.ntiles = 0;
     if ((long long)a.ptiles * ((Cout + 127) / 128) * (Cin / 64) >= (1LL << 29)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    return fuse_pool2 ? launch_halo3<true>(a, s) : launch_halo3<false>(a, s);
+    return fuse_pool2 ? launch_halo3<E, true>(a, s) : launch_halo3<E, false>(a, s);
+}
+
+extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                                       int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+    return halo3_dispatch<ElemBF16>(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+}
+extern "C" int cvpce_conv3x3_halo_wide_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
+                                           int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+    return halo3_dispatch<ElemF16>(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void decode_m(const ConvArgs& a, int m, int& img, int
 
 // Epilogue shared by both kernels: lane owns pixel (lane&31) of each 32-wide
 // pixel tile and channels 8g + 4h + {0..3} of each 32-channel tile.
-template <int MT, int NT>
+template <typename E, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int c_base, int p_base, int lane) {
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -117,7 +117,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                         if (co + j < a.Cout) {
                             float x = v[j];
                             if (a.bias) x += a.bias[co + j];
-                            if (a.res_mode) x += bf16_to_f32(a.res[res_pix * a.Cout + co + j]);
+                            if (a.res_mode) x += E::widen(a.res[res_pix * a.Cout + co + j]);
                             if (a.relu == 1) x = fmaxf(x, 0.f);
                             else if (a.relu == 2) x = tanhf(x);
                             o[co + j] = x;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     if (m_ok && co < a.Cout && (lane & 3) == 0) {
                         bf16x4 o;
 #pragma unroll
-                        for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+                        for (int j = 0; j < 1; ++j) o = E::pack4(f32x4{v[0], v[1], v[2], v[3]});
                         *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)(m >> 2) * a.Cout + co) = o;
                     }
                 } else {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     if (a.res_mode) {
                         const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + res_pix * a.Cout + co);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r[j]);
+                        for (int j = 0; j < 4; ++j) v[j] += E::widen(r[j]);
                     }
                     if (a.relu == 1) {
 #pragma unroll
@@ -161,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     }
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+                    for (int j = 0; j < 1; ++j) o = E::pack4(f32x4{v[0], v[1], v[2], v[3]});
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
                 }
             }
@@ -171,7 +171,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 
 // Epilogue for the 16x16x32 accumulator layout: lane owns pixel (lane&15) of each 16-pixel block and channels
 // 4*(lane>>4) + {0..3} of each 16-channel block.
-template <int MT, int NT>
+template <typename E, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[MT][NT], int c_base, int p_base, int lane) {
     const int lp = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -201,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
                     if (co + j < a.Cout) {
                         float x = v[j];
                         if (a.bias) x += a.bias[co + j];
-                        if (a.res_mode) x += bf16_to_f32(a.res[res_pix * a.Cout + co + j]);
+                        if (a.res_mode) x += E::widen(a.res[res_pix * a.Cout + co + j]);
                         if (a.relu == 1) x = fmaxf(x, 0.f);
                         else if (a.relu == 2) x = tanhf(x);
                         o[co + j] = x;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
                 if (m_ok && co < a.Cout && (lane & 3) == 0) {
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+                    for (int j = 0; j < 1; ++j) o = E::pack4(f32x4{v[0], v[1], v[2], v[3]});
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)(m >> 2) * a.Cout + co) = o;
                 }
             } else {
@@ -235,7 +235,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
                 if (a.res_mode) {
                     const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.res + res_pix * a.Cout + co);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += bf16_to_f32(r[j]);
+                    for (int j = 0; j < 4; ++j) v[j] += E::widen(r[j]);
                 }
                 if (a.relu == 1) {
 #pragma unroll
@@ -243,7 +243,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
                 }
                 bf16x4 o;
 #pragma unroll
-                for (int j = 0; j < 1; ++j) o = f32x4_to_bf16x4(f32x4{v[0], v[1], v[2], v[3]});
+                for (int j = 0; j < 1; ++j) o = E::pack4(f32x4{v[0], v[1], v[2], v[3]});
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.Cout + co) = o;
             }
         }
@@ -251,7 +251,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
 }
 
 // One K-step (BK) of MFMAs from a swizzled [rows][BK] LDS image pair.
-template <int MT, int NT, int BK>
+template <typename E, int MT, int NT, int BK>
 __device__ __forceinline__ void mfma_kstep(const bf16_t* Wb, const bf16_t* Pb, int wrow0, int prow0, int lane,
                                            f32x16 (&acc)[MT][NT]) {
     constexpr int CPR = BK / 8, RPB = 256 / (BK * 2);
@@ -274,14 +274,14 @@ __device__ __forceinline__ void mfma_kstep(const bf16_t* Wb, const bf16_t* Pb, i
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = E::mfma32(af[mt], bfr[nt], acc[mt][nt]);
     }
 }
 
 // ===========================================================================
 // LDS-DMA kernel
 // ===========================================================================
-template <int TC, int TP, int WC, int WP, int MINW>
+template <typename E, int TC, int TP, int WC, int WP, int MINW>
 __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma_kernel(ConvArgs a) {
     constexpr int BK = 64;
     constexpr int NW = WC * WP;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma_kernel(ConvArgs a
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][mt], bfr[kk & 1][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = E::mfma32(af[kk & 1][mt], bfr[kk & 1][nt], acc[mt][nt]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma_kernel(ConvArgs a
     }
 #undef CVPCE_DMA_ADDR
 #undef CVPCE_DMA_ISSUE
-    conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+    conv_epilogue<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
 // ===========================================================================
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma_kernel(ConvArgs a
 // K-steps (4 x 32 KiB at 256x256): stage t+3 is issued while stage t computes, the wave waits with
 // a COUNTED vmcnt (never 0 in steady state) and a raw s_barrier (a __syncthreads() would drain
 // vmcnt to 0).  K order: (64-channel chunk, kh, kw, 32-channel half, channel).
-template <int TC, int TP, int WC, int WP, int MINW, int NS>
+template <typename E, int TC, int TP, int WC, int WP, int MINW, int NS>
 __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs a) {
     constexpr int BK = 32;
     static_assert(NS == 3 || NS == 4, "ring depth");
@@ -582,13 +582,13 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                \
                 f32x4* q4 = reinterpret_cast<f32x4*>(&acc[mt][nt]);                                            \
-                q4[2 * (SLOT)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SLOT][mt], bfr[SLOT][nt], q4[2 * (SLOT)], 0, 0, 0); \
-                q4[2 * (SLOT) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SLOT][mt], bfr[SLOT][nt], q4[2 * (SLOT) + 1], 0, 0, 0); \
+                q4[2 * (SLOT)] = E::mfma16(af[SLOT][mt], bfr[SLOT][nt], q4[2 * (SLOT)]); \
+                q4[2 * (SLOT) + 1] = E::mfma16(af[SLOT][mt], bfr[SLOT][nt], q4[2 * (SLOT) + 1]); \
             }                                                                                                  \
         } else if (!(CVPCE_DBG & 8)) {                                                                         \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                      \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SLOT][mt], bfr[SLOT][nt], acc[mt][nt], 0, 0, 0); \
+                acc[mt][nt] = E::mfma32(af[SLOT][mt], bfr[SLOT][nt], acc[mt][nt]); \
         }                                                                                                      \
         __builtin_amdgcn_s_setprio(0);                                                                         \
     }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
 #undef CVPCE_FRAGS
 #undef CVPCE_MFMAS
 #undef CVPCE_DMA4_STAGE
-    conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+    conv_epilogue<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
 // ===========================================================================
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
 // K-steps (4 x 32 KiB at 256x256): stage t+3 is issued while stage t computes, the wave waits with
 // a COUNTED vmcnt (never 0 in steady state) and a raw s_barrier (a __syncthreads() would drain
 // vmcnt to 0).  K order: (64-channel chunk, kh, kw, 32-channel half, channel).
-template <int TC, int TP, int WC, int WP, int MINW, int NS>
+template <typename E, int TC, int TP, int WC, int WP, int MINW, int NS>
 __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs a) {
     constexpr int BK = 32;
     static_assert(NS == 3 || NS == 4, "ring depth");
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs
         __builtin_amdgcn_s_setprio(1);                                                                         \
         _Pragma("unroll") for (int i = 0; i < MH; ++i)                                                         \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
-                acc[(M0) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(M0) + i], bfr[SET][nt], acc[(M0) + i][nt], 0, 0, 0); \
+                acc[(M0) + i][nt] = E::mfma16(af[(M0) + i], bfr[SET][nt], acc[(M0) + i][nt]); \
         __builtin_amdgcn_s_setprio(0);                                                                         \
     }
     // stage 0 becomes visible; fetch its group 0
@@ -826,13 +826,13 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs
 #undef CVPCE_READ_B
 #undef CVPCE_MFMAS
 #undef CVPCE_DMA4_STAGE
-    conv_epilogue16<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+    conv_epilogue16<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
 // ===========================================================================
 // generic register-staged kernel
 // ===========================================================================
-template <int TC, int TP, int BK, int WC, int WP>
+template <typename E, int TC, int TP, int BK, int WC, int WP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int CPR = BK / 8;             // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;          // tile rows covered per staging pass
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     {                                                                                                          \
         CVPCE_LOAD_TILE((KT) + 2, (SLOT) ^ 1)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        mfma_kstep<MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc); \
+        mfma_kstep<E, MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc); \
         CVPCE_STORE_TILE(cur ^ 1, SLOT)                                                                        \
         __syncthreads();                                                                                       \
         cur ^= 1;                                                                                              \
@@ -966,21 +966,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #undef CVPCE_KSTEP
 #undef CVPCE_LOAD_TILE
 #undef CVPCE_STORE_TILE
-    conv_epilogue<MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+    conv_epilogue<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
-template <int TC, int TP, int BK, int WC, int WP>
+template <typename E, int TC, int TP, int BK, int WC, int WP>
 static int launch_conv(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_p = (a.M + TP - 1) / TP;
     a.tiles_c = (a.Cout + TC - 1) / TC;
     size_t smem = (size_t)2 * (TC + TP) * BK * sizeof(bf16_t);
     dim3 grid(a.tiles_p * a.tiles_c);
-    hipLaunchKernelGGL((conv_igemm_kernel<TC, TP, BK, WC, WP>), grid, dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, BK, WC, WP>), grid, dim3(256), smem, stream, a);
     return cvpce_check_launch();
 }
 
-template <int TC, int TP, int WC, int WP, int MINW>
+template <typename E, int TC, int TP, int WC, int WP, int MINW>
 static int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_p = (a.M + TP - 1) / TP;
@@ -988,17 +988,17 @@ static int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
     const size_t smem = (size_t)2 * (TC + TP) * 64 * sizeof(bf16_t);
     static bool attr_set = false;     // one flag per template instance
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma_kernel<TC, TP, WC, WP, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv_dma_kernel<E, TC, TP, WC, WP, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     dim3 grid(a.tiles_p * a.tiles_c);
-    hipLaunchKernelGGL((conv_dma_kernel<TC, TP, WC, WP, MINW>), grid, dim3(WC * WP * 64), smem, stream, a);
+    hipLaunchKernelGGL((conv_dma_kernel<E, TC, TP, WC, WP, MINW>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();
 }
 
-template <int TC, int TP, int WC, int WP, int MINW, int NS>
+template <typename E, int TC, int TP, int WC, int WP, int MINW, int NS>
 static int launch_conv_dma4(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_p = (a.M + TP - 1) / TP;
@@ -1006,17 +1006,17 @@ static int launch_conv_dma4(const ConvArgs& a0, hipStream_t stream) {
     const size_t smem = (size_t)NS * (TC + TP) * 32 * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma4_kernel<TC, TP, WC, WP, MINW, NS>,
+        if (hipFuncSetAttribute((const void*)conv_dma4_kernel<E, TC, TP, WC, WP, MINW, NS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     dim3 grid(a.tiles_p * a.tiles_c);
-    hipLaunchKernelGGL((conv_dma4_kernel<TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
+    hipLaunchKernelGGL((conv_dma4_kernel<E, TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();
 }
 
-template <int TC, int TP, int WC, int WP, int MINW, int NS>
+template <typename E, int TC, int TP, int WC, int WP, int MINW, int NS>
 static int launch_conv_dma16(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_p = (a.M + TP - 1) / TP;
@@ -1024,21 +1024,22 @@ static int launch_conv_dma16(const ConvArgs& a0, hipStream_t stream) {
     const size_t smem = (size_t)NS * (TC + TP) * 32 * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma16_kernel<TC, TP, WC, WP, MINW, NS>,
+        if (hipFuncSetAttribute((const void*)conv_dma16_kernel<E, TC, TP, WC, WP, MINW, NS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     dim3 grid(a.tiles_p * a.tiles_c);
-    hipLaunchKernelGGL((conv_dma16_kernel<TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
+    hipLaunchKernelGGL((conv_dma16_kernel<E, TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();
 }
 
-extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res,
-                                      void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                                      int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
-                                      int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
-                                      int fuse_pool2, int force_generic, void* stream) {
+template <typename E>
+static int conv2d_dispatch(const void* in, const void* wgt, const float* bias, const void* res,
+                           void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                           int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
+                           int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
+                           int fuse_pool2, int force_generic, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (Cin % 8 != 0 || K_pad % 32 != 0 || (Cin % 64 == 0 && K_pad % 64 != 0) || Cout_pad % 256 != 0 || Cout_pad < Cout)
@@ -1069,15 +1070,33 @@ extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const flo
     const long long tiles256 = ((long long)a.M + 255) / 256;
     if (bk64 && force_generic != 1) {
         if (Cout >= 192 && tiles256 * ((Cout + 255) / 256) >= 128)
-            return (force_generic == 2 || in_up_shift || KH * KW > 32) ? launch_conv_dma<256, 256, 2, 4, 2>(a, s)
-                   : (force_generic == 3)                                ? launch_conv_dma4<256, 256, 2, 4, 2, 4>(a, s)
-                                                                        : launch_conv_dma16<256, 256, 2, 4, 2, 4>(a, s);
-        if (Cout > 64 && Cout <= 128 && tiles256 >= 128) return launch_conv_dma<128, 128, 2, 2, 2>(a, s);
-        if (Cout > 32 && Cout <= 64 && tiles256 >= 128) return launch_conv_dma<64, 128, 2, 2, 2>(a, s);
+            return (force_generic == 2 || in_up_shift || KH * KW > 32) ? launch_conv_dma<E, 256, 256, 2, 4, 2>(a, s)
+                   : (force_generic == 3)                                ? launch_conv_dma4<E, 256, 256, 2, 4, 2, 4>(a, s)
+                                                                        : launch_conv_dma16<E, 256, 256, 2, 4, 2, 4>(a, s);
+        if (Cout > 64 && Cout <= 128 && tiles256 >= 128) return launch_conv_dma<E, 128, 128, 2, 2, 2>(a, s);
+        if (Cout > 32 && Cout <= 64 && tiles256 >= 128) return launch_conv_dma<E, 64, 128, 2, 2, 2>(a, s);
     }
     if (Cout > 64) {
-        return bk64 ? launch_conv<128, 128, 64, 2, 2>(a, s) : launch_conv<128, 128, 32, 2, 2>(a, s);
+        return bk64 ? launch_conv<E, 128, 128, 64, 2, 2>(a, s) : launch_conv<E, 128, 128, 32, 2, 2>(a, s);
     } else {
-        return bk64 ? launch_conv<64, 128, 64, 2, 2>(a, s) : launch_conv<64, 128, 32, 2, 2>(a, s);
+        return bk64 ? launch_conv<E, 64, 128, 64, 2, 2>(a, s) : launch_conv<E, 64, 128, 32, 2, 2>(a, s);
     }
 }
+
+#define CVPCE_CONV2D_ARGS in, wgt, bias, res, out, N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, K_pad, Cout_pad, act, out_f32, \
+                          in_up_shift, res_mode, Hr, Wr, fuse_pool2, force_generic, stream
+extern "C" int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res,
+                                      void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                      int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
+                                      int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
+                                      int fuse_pool2, int force_generic, void* stream) {
+    return conv2d_dispatch<ElemBF16>(CVPCE_CONV2D_ARGS);
+}
+extern "C" int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const float* bias, const void* res,
+                                     void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                     int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
+                                     int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
+                                     int fuse_pool2, int force_generic, void* stream) {
+    return conv2d_dispatch<ElemF16>(CVPCE_CONV2D_ARGS);
+}
+#undef CVPCE_CONV2D_ARGS

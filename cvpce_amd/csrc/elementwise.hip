@@ -6,13 +6,15 @@
 #include "../../include/cvpce_amd.h"
 #include <math.h>
 
-__device__ __forceinline__ uint4 max_bf16x8(uint4 a, uint4 b) {
+template <typename E>
+__device__ __forceinline__ uint4 max_elem8(uint4 a, uint4 b) {
     bf16x8 x = *reinterpret_cast<bf16x8*>(&a), y = *reinterpret_cast<bf16x8*>(&b), r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = ((float)x[i] > (float)y[i]) ? x[i] : y[i];
+    for (int i = 0; i < 8; ++i) r[i] = (E::widen(x[i]) > E::widen(y[i])) ? x[i] : y[i];
     return *reinterpret_cast<uint4*>(&r);
 }
 
+template <typename E>
 __global__ void maxpool_nhwc_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int N, int H, int W,
                                     int C, int k, int stride, int pad, int Ho, int Wo) {
     const int C8 = C / 8;
@@ -27,7 +29,7 @@ __global__ void maxpool_nhwc_kernel(const bf16_t* __restrict__ in, bf16_t* __res
         int n = (int)(p / Ho);
         bf16x8 neg;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) neg[j] = (bf16_t)(-INFINITY);
+        for (int j = 0; j < 8; ++j) neg[j] = E::kF16 ? __builtin_bit_cast(bf16_t, (f16_t)(-INFINITY)) : (bf16_t)(-INFINITY);
         uint4 acc = *reinterpret_cast<uint4*>(&neg);
         for (int dy = 0; dy < k; ++dy) {
             int iy = oy * stride - pad + dy;
@@ -36,43 +38,60 @@ __global__ void maxpool_nhwc_kernel(const bf16_t* __restrict__ in, bf16_t* __res
                 int ix = ox * stride - pad + dx;
                 if ((unsigned)ix >= (unsigned)W) continue;
                 uint4 v = *reinterpret_cast<const uint4*>(in + ((size_t)(n * H + iy) * W + ix) * C + c8 * 8);
-                acc = max_bf16x8(acc, v);
+                acc = max_elem8<E>(acc, v);
             }
         }
         *reinterpret_cast<uint4*>(out + ((size_t)(n * Ho + oy) * Wo + ox) * C + c8 * 8) = acc;
     }
 }
 
-extern "C" int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride,
-                                         int pad, int Ho, int Wo, void* stream) {
+template <typename E>
+static int maxpool_dispatch(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, void* stream) {
     if (!in || !out || C % 8 != 0 || k < 1 || stride < 1) return CVPCE_ERR_ARG;
     if (Ho != (H + 2 * pad - k) / stride + 1 || Wo != (W + 2 * pad - k) / stride + 1) return CVPCE_ERR_ARG;
     long long total = (long long)N * Ho * Wo * (C / 8);
     if (total <= 0) return CVPCE_OK;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+    hipLaunchKernelGGL(maxpool_nhwc_kernel<E>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
                        (bf16_t*)out, N, H, W, C, k, stride, pad, Ho, Wo);
     return cvpce_check_launch();
 }
 
-__global__ void relu_bf16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long n8) {
+extern "C" int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, int C, int k, int stride,
+                                         int pad, int Ho, int Wo, void* stream) {
+    return maxpool_dispatch<ElemBF16>(in, out, N, H, W, C, k, stride, pad, Ho, Wo, stream);
+}
+extern "C" int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int C, int k, int stride,
+                                        int pad, int Ho, int Wo, void* stream) {
+    return maxpool_dispatch<ElemF16>(in, out, N, H, W, C, k, stride, pad, Ho, Wo, stream);
+}
+
+// ReLU on 16-bit sign-magnitude floats (bf16 and fp16 alike): positive values pass, everything else -- negatives, -0, and
+// like `(float)x > 0 ? x : 0` NaNs -- becomes +0.
+__global__ void relu_bf16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long n8, int is_f16) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         uint4 v = in[i];
-        bf16x8 x = *reinterpret_cast<bf16x8*>(&v);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 x = *reinterpret_cast<s16x8*>(&v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = ((float)x[j] > 0.f) ? x[j] : (bf16_t)0.f;
+        for (int j = 0; j < 8; ++j) {
+            const int mag = x[j] & 0x7FFF, inf = is_f16 ? 0x7C00 : 0x7F80;      // positive and not NaN
+            x[j] = (x[j] > 0 && mag <= inf) ? x[j] : (short)0;
+        }
         out[i] = *reinterpret_cast<uint4*>(&x);
     }
 }
 
-extern "C" int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream) {
+static int relu_dispatch(const void* in, void* out, long long n, int is_f16, void* stream) {
     if (!in || !out || n % 8 != 0) return CVPCE_ERR_ARG;
     long long n8 = n / 8;
     if (n8 == 0) return CVPCE_OK;
     int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(relu_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n8);
+    hipLaunchKernelGGL(relu_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n8, is_f16);
     return cvpce_check_launch();
 }
+extern "C" int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream) { return relu_dispatch(in, out, n, 0, stream); }
+extern "C" int cvpce_relu_f16(const void* in, void* out, long long n, void* stream) { return relu_dispatch(in, out, n, 1, stream); }
 
 // Global max over H*W for each (image, channel): block = (64-channel slab, image);
 // 256 threads = 8 channel-octets x 32 pixel lanes, 16 B loads, LDS tree over the pixel lanes.

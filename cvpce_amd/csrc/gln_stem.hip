@@ -36,6 +36,7 @@ struct GlnStemArgs {
     int N, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y;
 };
 
+template <typename E>
 __global__ __launch_bounds__(GS_THREADS) void gln_stem_kernel(GlnStemArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char IN[GS_IN_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char CV[GS_CONV_BYTES];
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(GS_THREADS) void gln_stem_kernel(GlnStemArgs a) {
         for (int s = 0; s < 14; ++s)                       // s = kh*2 + h: pixels 2cx + 4h + 2lh, +1 of row 2cy + kh
             bfr[s] = *reinterpret_cast<const bf16x8*>(src + ((s >> 1) * GS_IP + 4 * (s & 1)) * 8);
 #pragma unroll
-        for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bfr[s], acc, 0, 0, 0);
+        for (int s = 0; s < 14; ++s) acc = E::mfma32(wf[s], bfr[s], acc);
         const int y = cy0 + cy, x = cx0 + cx;
         const unsigned keep = ((unsigned)y < (unsigned)a.Hc && (unsigned)x < (unsigned)a.Wc) ? 0xFFFFFFFFu : 0u;
         if (real) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(GS_THREADS) void gln_stem_kernel(GlnStemArgs a) {
                 f32x4 r;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[j] = relu_bits(acc[4 * g + j]);
-                uint2 u = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r));
+                uint2 u = __builtin_bit_cast(uint2, E::pack4(r));
                 u.x &= keep;
                 u.y &= keep;
                 *reinterpret_cast<uint2*>(dst + g * 16) = u;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(GS_THREADS) void gln_stem_kernel(GlnStemArgs a) {
     }
     __syncthreads();
 
-    // 3x3 stride-2 max-pool of the 17x17 tile: thread <-> (pooled pixel, 4-channel chunk); non-negative bf16 compare as int16
+    // 3x3 stride-2 max-pool of the 17x17 tile: thread <-> (pooled pixel, 4-channel chunk); non-negative bf16 / fp16 values compare as int16
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     for (int i = tid; i < GS_PT * GS_PT * 16; i += GS_THREADS) {
         const int ch = i & 15, pp = i >> 4;
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(GS_THREADS) void gln_stem_kernel(GlnStemArgs a) {
 // in: N x H x W x 8 bf16 (what cvpce_gln_transform writes); w_frag: the 64 x (7 x 8 x 4) weights in MFMA fragment order
 // [ct][kh*2+h][lane][8] with lane = lh*32 + cout%32 holding kw = 4h + 2lh + j/4, channel j%4 (zeros for kw = 7 and
 // channel 3); bias: 64 floats; out: N x Hp x Wp x 64 bf16 with Hc = (H - 1)/2 + 1, Hp = (Hc - 1)/2 + 1.
-extern "C" int cvpce_gln_stem_fused(const void* in, const void* w_frag, const float* bias, void* out, int N, int H, int W,
-                                    void* stream) {
+template <typename E>
+static int gln_stem_dispatch(const void* in, const void* w_frag, const float* bias, void* out, int N, int H, int W, void* stream) {
     if (!in || !w_frag || !bias || !out || N <= 0 || H <= 0 || W <= 0) return CVPCE_ERR_ARG;
     GlnStemArgs a;
     a.in = (const unsigned char*)in;
@@ -145,6 +146,15 @@ extern "C" int cvpce_gln_stem_fused(const void* in, const void* w_frag, const fl
     a.tiles_y = (a.Hp + GS_PT - 1) / GS_PT; a.tiles_x = (a.Wp + GS_PT - 1) / GS_PT;
     const long long blocks = (long long)N * a.tiles_x * a.tiles_y;
     if (blocks > 0x7FFFFFFFLL || (long long)N * H * W * 16 > 0xFFFFFFFFFFLL) return CVPCE_ERR_ARG;
-    hipLaunchKernelGGL(gln_stem_kernel, dim3((unsigned)blocks), dim3(GS_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gln_stem_kernel<E>, dim3((unsigned)blocks), dim3(GS_THREADS), 0, (hipStream_t)stream, a);
     return cvpce_check_launch();
+}
+
+extern "C" int cvpce_gln_stem_fused(const void* in, const void* w_frag, const float* bias, void* out, int N, int H, int W,
+                                    void* stream) {
+    return gln_stem_dispatch<ElemBF16>(in, w_frag, bias, out, N, H, W, stream);
+}
+extern "C" int cvpce_gln_stem_fused_f16(const void* in, const void* w_frag, const float* bias, void* out, int N, int H, int W,
+                                        void* stream) {
+    return gln_stem_dispatch<ElemF16>(in, w_frag, bias, out, N, H, W, stream);
 }

@@ -24,6 +24,7 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
     l0 = 1.f - l1;
 }
 
+template <typename E>
 __global__ void gln_transform_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int H0, int W0, int h,
                                      int w, int Hp, int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -31,7 +32,7 @@ __global__ void gln_transform_kernel(const float* __restrict__ img, bf16_t* __re
     if (x >= Wp) return;
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;     // (+0 has the same bits in bf16 and fp16)
     if (y < h && x < w) {
         const float sy = (float)H0 / (float)h, sx = (float)W0 / (float)w;
         int y0, y1, x0, x1;
@@ -47,20 +48,30 @@ __global__ void gln_transform_kernel(const float* __restrict__ img, bf16_t* __re
             float v10 = (p[(size_t)y1 * W0 + x0] - mean[c]) / stdv[c];
             float v11 = (p[(size_t)y1 * W0 + x1] - mean[c]) / stdv[c];
             float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-            o[c] = f32_to_bf16(v);
+            o[c] = E::narrow(v);
         }
     }
     *reinterpret_cast<bf16x8*>(out + ((size_t)y * Wp + x) * 8) = o;
 }
 
-extern "C" int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
-                                   const float* mean3, const float* std3, void* stream) {
+template <typename E>
+static int gln_transform_dispatch(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
+                                  const float* mean3, const float* std3, void* stream) {
     if (!img || !out_nhwc8 || !mean3 || !std3) return CVPCE_ERR_ARG;
     if (h > Hp || w > Wp || h <= 0 || w <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
     dim3 grid((Wp + 127) / 128, Hp);
-    hipLaunchKernelGGL(gln_transform_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, (bf16_t*)out_nhwc8, H0, W0,
+    hipLaunchKernelGGL(gln_transform_kernel<E>, grid, dim3(128), 0, (hipStream_t)stream, img, (bf16_t*)out_nhwc8, H0, W0,
                        h, w, Hp, Wp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     return cvpce_check_launch();
+}
+
+extern "C" int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
+                                   const float* mean3, const float* std3, void* stream) {
+    return gln_transform_dispatch<ElemBF16>(img, out_nhwc8, H0, W0, h, w, Hp, Wp, mean3, std3, stream);
+}
+extern "C" int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
+                                       const float* mean3, const float* std3, void* stream) {
+    return gln_transform_dispatch<ElemF16>(img, out_nhwc8, H0, W0, h, w, Hp, Wp, mean3, std3, stream);
 }
 
 // One block row per (crop, output row); boxes are read on the device (no host sync).

@@ -236,8 +236,15 @@ def resized_hw(h, w):
 class GLNEngine:
     """Weights packed for the HIP kernels (bf16 [Cout][K], FrozenBN/BN folded) + the launch schedule."""
 
-    def __init__(self, model, device):
-        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, **kw)
+    def __init__(self, model, device, precision='bf16'):
+        """precision: storage type of the detector's weights and inter-layer activations -- 'bf16' (default; what BASELINE's
+        configs name) or 'fp16' (the accuracy mode: 10 instead of 7 mantissa bits at the same MFMA rate; head logits, box
+        regressions and gaussians are fp32 in both)."""
+        if precision not in ops.STORAGE_TYPES:
+            raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
+        self.precision = precision
+        self.dtype = dt = ops.STORAGE_TYPES[precision]
+        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, dtype=dt, **kw)
         body = model.backbone.body
 
         def fold(conv, bn):
@@ -245,7 +252,7 @@ class GLNEngine:
             return P(conv, scale=s, shift=b)
 
         self.stem = fold(body.conv1, body.bn1)
-        self.stem_fused = ops.PackedGlnStem(body.conv1.weight, *body.bn1.affine(), device=device) if tuple(body.conv1.weight.shape) == (64, 3, 7, 7) else None
+        self.stem_fused = ops.PackedGlnStem(body.conv1.weight, *body.bn1.affine(), device=device, dtype=dt) if tuple(body.conv1.weight.shape) == (64, 3, 7, 7) else None
         self.layers = []
         for li in range(4):
             blocks = []
@@ -270,7 +277,7 @@ class GLNEngine:
 
     def pack_gaussian(self, gl, subnet, device):
         """Gaussian branch weights (proposals.py:65-107): eval-mode BatchNorm folded into block1/block2."""
-        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, **kw)
+        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, dtype=self.dtype, **kw)
 
         def fold_bn(blk):
             bn = blk.norm
@@ -302,8 +309,8 @@ class GLNEngine:
 
     def transform(self, images, out=None):
         sizes, rs, (hp, wp) = self.batch_geometry(images)
-        batch = out if out is not None else torch.empty((len(images), hp, wp, 8), dtype=torch.bfloat16, device=self.device)
-        assert tuple(batch.shape) == (len(images), hp, wp, 8)
+        batch = out if out is not None else torch.empty((len(images), hp, wp, 8), dtype=self.dtype, device=self.device)
+        assert tuple(batch.shape) == (len(images), hp, wp, 8) and batch.dtype == self.dtype
         for i, (img, (h, w)) in enumerate(zip(images, rs)):
             ops.gln_transform_into(img.contiguous(), batch, i, h, w, IMAGE_MEAN, IMAGE_STD)
         return batch, sizes, rs
@@ -413,7 +420,7 @@ class GLNEngine:
         if bkey not in bufs:
             if len(bufs) >= MAX_DETECT_GRAPHS:
                 bufs.pop(next(iter(bufs)))
-            bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=torch.bfloat16, device=self.device) for _ in range(5)]
+            bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=self.dtype, device=self.device) for _ in range(5)]
         atlas, cls_a, cls_b, reg_a, reg_b = bufs[bkey]
         self._keep(bufs[bkey])
         if USE_ATLAS_COPY:
@@ -533,7 +540,7 @@ class GLNEngine:
             batch, original, resized = self.transform(images)
             return self._detect_tail(batch, original, resized, num_classes, detections_per_img, conf_thresh, False)
         if entry['graph'] is None:                         # second call: capture
-            static_in = torch.empty((len(images), padded[0], padded[1], 8), dtype=torch.bfloat16, device=self.device)
+            static_in = torch.empty((len(images), padded[0], padded[1], 8), dtype=self.dtype, device=self.device)
             self.transform(images, out=static_in)
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
@@ -578,8 +585,11 @@ class GaussianLayerNetwork(nn.Module):
     """Drop-in for proposals.py:162-181 (eval mode): `model(list[Tensor(3,H,W)])` ->
     `list[dict(boxes, scores, labels, gaussians)]`, boxes in original pixels, scores descending."""
 
-    def __init__(self, resnet, num_classes, gaussian_loss_params={}, tanh=False, detections_per_img=1000, **kwargs):
+    def __init__(self, resnet, num_classes, gaussian_loss_params={}, tanh=False, detections_per_img=1000, precision='bf16', **kwargs):
         super().__init__()
+        if precision not in ops.STORAGE_TYPES:
+            raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
+        self.precision = precision
         if kwargs:
             raise TypeError(f'unsupported RetinaNet overrides on the HIP path: {sorted(kwargs)}')
         self.backbone = BackboneWithFPNAndGaussians(resnet, tanh=tanh)
@@ -594,6 +604,16 @@ class GaussianLayerNetwork(nn.Module):
         self._engine = None
         return super().load_state_dict(*args, **kwargs)
 
+    def set_precision(self, precision):
+        """'bf16' (default) | 'fp16' (accuracy mode): storage type of the detector's weights / activations on the GPU.  The
+        parameters themselves stay fp32 (checkpoint format unchanged); the engine is re-packed on the next forward."""
+        if precision not in ops.STORAGE_TYPES:
+            raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
+        if precision != self.precision:
+            self.precision = precision
+            self._engine = None
+        return self
+
     def _apply(self, fn, *a, **k):
         self._engine = None
         return super()._apply(fn, *a, **k)
@@ -604,7 +624,7 @@ class GaussianLayerNetwork(nn.Module):
             raise RuntimeError('GaussianLayerNetwork runs on an MI355X (HIP) device only: call .cuda() first. '
                                'No CPU fallback exists in cvpce_amd (the CPU restatement lives in oracle/ for tests).')
         if self._engine is None:
-            self._engine = GLNEngine(self, dev)
+            self._engine = GLNEngine(self, dev, self.precision)
         return self._engine
 
     @torch.no_grad()
@@ -638,7 +658,7 @@ def gln_backbone(trainable_layers=5, pretrained=True):
 
 
 def gln(num_classes=1, trainable_layers=4, pretrained_backbone=True, tanh=False, gaussian_loss_params={},
-        detections_per_img=1000):
-    """proposals.py:202-203"""
+        detections_per_img=1000, precision='bf16'):
+    """proposals.py:202-203 (+ `precision`, keyword-only in spirit: 'bf16' | 'fp16' storage of the detector on the GPU)"""
     return GaussianLayerNetwork(gln_backbone(trainable_layers, pretrained_backbone), num_classes, tanh=tanh,
-                                gaussian_loss_params=gaussian_loss_params, detections_per_img=detections_per_img)
+                                gaussian_loss_params=gaussian_loss_params, detections_per_img=detections_per_img, precision=precision)

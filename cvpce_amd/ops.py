@@ -17,6 +17,14 @@ from ._lib import lib, check
 from .torch_ops import T
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+STORAGE_TYPES = {'bf16': BF16, 'fp16': F16}    # element types the detector's kernels exist for (csrc/common.h ElemBF16 / ElemF16)
+F16_MAX = 65504.0
+
+
+def to_storage(t, dtype):
+    """f32 host tensor -> the 16-bit storage type, RNE; fp16 saturates at +-65504 like the kernels' epilogues."""
+    return t.clamp(-F16_MAX, F16_MAX).to(F16) if dtype == F16 else t.to(dtype)
 
 
 def _stream():
@@ -40,9 +48,12 @@ def _need_cuda(*ts):
 class PackedConv:
     """bf16 [Cout_pad][K_pad] weight + fp32 bias in the K order of include/cvpce_amd.h."""
 
-    def __init__(self, weight, bias=None, stride=1, pad=0, scale=None, shift=None, device='cuda'):
+    def __init__(self, weight, bias=None, stride=1, pad=0, scale=None, shift=None, device='cuda', dtype=BF16):
         """weight (Cout,Cin,KH,KW) f32; optional per-Cout affine folded in:
-        y = conv(x, w) * scale + shift (+ bias * scale)  -- FrozenBN / BN-eval folding."""
+        y = conv(x, w) * scale + shift (+ bias * scale)  -- FrozenBN / BN-eval folding.
+        dtype: storage type of the packed weight = the activations' type this layer runs on (bf16 | fp16)."""
+        assert dtype in (BF16, F16)
+        self.dtype = dtype
         w = weight.detach().to(torch.float32).cpu()
         cout, cin, kh, kw = w.shape
         b = bias.detach().to(torch.float32).cpu() if bias is not None else None
@@ -67,7 +78,7 @@ class PackedConv:
             wp = wp.reshape(self.cout_pad, kh, kw, self.cin_pad // 64, 64).permute(0, 3, 1, 2, 4)
         packed = torch.zeros(self.cout_pad, self.k_pad, dtype=torch.float32)
         packed[:, :k] = wp.reshape(self.cout_pad, k)
-        self.weight = packed.to(BF16).to(device)
+        self.weight = to_storage(packed, dtype).to(device)
         self.bias = b.to(device) if b is not None else None
 
     def out_hw(self, h, w, in_up_shift=0):
@@ -121,18 +132,18 @@ FORCE_GENERIC_CONV = False   # A/B switch: route every conv through the register
 
 
 def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0, out=None, pool=False):
-    """x: NHWC bf16 (N,H,W,Cin_pad) -> NHWC (N,Ho,Wo,Cout) bf16 | f32."""
+    """x: NHWC bf16 | fp16 (N,H,W,Cin_pad), the type `pc` was packed for -> NHWC (N,Ho,Wo,Cout) of the same type | f32."""
     _need_cuda(x, residual)
-    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    assert x.dtype == pc.dtype and x.is_contiguous() and x.dim() == 4, (x.dtype, pc.dtype)
     n, h, w, cin = x.shape
     assert cin == pc.cin_pad, (cin, pc.cin_pad)
     ho, wo = pc.out_hw(h, w, in_up_shift)
     if out is None:
         oshape = (n, ho // 2, wo // 2, pc.cout) if pool else (n, ho, wo, pc.cout)
-        out = torch.empty(oshape, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        out = torch.empty(oshape, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     hr = wr = 0
     if residual is not None:
-        assert residual.dtype == BF16 and residual.is_contiguous() and residual.shape[0] == n and residual.shape[3] == pc.cout
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.shape[0] == n and residual.shape[3] == pc.cout
         hr, wr = residual.shape[1], residual.shape[2]
         if res_mode == 0:
             res_mode = 1 if (hr, wr) == (ho, wo) else 2
@@ -184,7 +195,7 @@ def conv2d_relu_mac(x, pc, mac, mac_off, store=True, pool=False):
     `mac` (N, D) f32 must be zero-filled.  store=False: the map is not written at all (returns None); pool=True: the
     returned map is MaxPool2d(2,2) of it (the descriptor is still over the unpooled map)."""
     _need_cuda(x, mac)
-    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mac.dtype == torch.float32 and mac.is_contiguous()
+    assert x.dtype == BF16 and pc.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mac.dtype == torch.float32 and mac.is_contiguous()
     assert can_fuse_mac(x, pc) and mac.shape[0] == x.shape[0] and mac_off + pc.cout <= mac.shape[1]
     n, h, w, cin = x.shape
     out = None
@@ -220,24 +231,25 @@ class PackedStem:
 class PackedGlnStem:
     """conv 7x7/2 (3->64) with its FrozenBatchNorm folded in, in the MFMA fragment order of cvpce_gln_stem_fused."""
 
-    def __init__(self, weight, scale, shift, device='cuda'):
+    def __init__(self, weight, scale, shift, device='cuda', dtype=BF16):
+        self.dtype = dtype
         w = weight.detach().to(torch.float32).cpu() * scale.detach().to(torch.float32).cpu()[:, None, None, None]
         assert tuple(w.shape) == (64, 3, 7, 7)
         slots = torch.zeros(64, 7, 8, 4)                       # (cout, kh, kw slot, channel slot)
         slots[:, :, :7, :3] = w.permute(0, 2, 3, 1)
         # [ct][kh][h][lh][r][kw_local 2][c 4]: kw = 4h + 2lh + kw_local
         f = slots.reshape(2, 32, 7, 2, 2, 2, 4).permute(0, 2, 3, 4, 1, 5, 6)
-        self.w_frag = f.reshape(2, 14, 64, 8).contiguous().to(BF16).to(device)
+        self.w_frag = to_storage(f.reshape(2, 14, 64, 8).contiguous(), dtype).to(device)
         self.bias = shift.detach().to(torch.float32).to(device)
 
 
 def gln_stem(x, ps):
-    """x: (N,H,W,8) bf16 transformed batch -> (N,Hp,Wp,64) bf16 = maxpool3x3/2(relu(bn(conv7x7/2(x))))."""
+    """x: (N,H,W,8) bf16 | fp16 transformed batch -> (N,Hp,Wp,64) of the same type = maxpool3x3/2(relu(bn(conv7x7/2(x))))."""
     _need_cuda(x)
-    assert x.dtype == BF16 and x.is_contiguous() and x.shape[3] == 8
+    assert x.dtype == ps.dtype and x.is_contiguous() and x.shape[3] == 8
     n, h, w, _ = x.shape
     hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    out = torch.empty((n, (hc - 1) // 2 + 1, (wc - 1) // 2 + 1, 64), dtype=BF16, device=x.device)
+    out = torch.empty((n, (hc - 1) // 2 + 1, (wc - 1) // 2 + 1, 64), dtype=x.dtype, device=x.device)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -263,15 +275,15 @@ def conv3x3_atlas(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None)
     gaps; mask (H,W) uint8 is 1 on level pixels.  Output pixels on the gaps are written as zeros.  tile_map (atlas_tile_map):
     only those tiles are computed -- `out` must then be given and hold zeros on the skipped (all-gap) tiles."""
     _need_cuda(x, mask, tile_map, out)
-    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4 and mask.dtype == torch.uint8 and mask.is_contiguous()
+    assert x.dtype == pc.dtype and x.is_contiguous() and x.dim() == 4 and mask.dtype == torch.uint8 and mask.is_contiguous()
     n, h, w, cin = x.shape
     assert tuple(mask.shape) == (h, w) and cin == pc.cin_pad and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad == 1
     assert pc.cin_pad % 64 == 0 and pc.cout % 8 == 0 and pc.cout > 128 and act in (0, 1)
     if tile_map is not None:
         assert out is not None and tile_map.dtype == torch.int32 and tile_map.is_contiguous()
     if out is None:
-        out = torch.empty((n, h, w, pc.cout), dtype=BF16, device=x.device)
-    assert tuple(out.shape) == (n, h, w, pc.cout) and out.dtype == BF16 and out.is_contiguous()
+        out = torch.empty((n, h, w, pc.cout), dtype=x.dtype, device=x.device)
+    assert tuple(out.shape) == (n, h, w, pc.cout) and out.dtype == x.dtype and out.is_contiguous()
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,7 +334,7 @@ def maxpool2d(x, k, stride, pad=0):
     _need_cuda(x)
     n, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    out = torch.empty((n, ho, wo, c), dtype=BF16, device=x.device)
+    out = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
     T.maxpool2d_nhwc(x, out, k, stride, pad)
     return out
 
@@ -353,7 +365,7 @@ def l2_normalize(desc, eps=1e-8, want_bf16=False):
 # input side
 # ---------------------------------------------------------------------------
 def gln_transform_into(img, batch, index, h, w, mean, std):
-    """img (3,H0,W0) f32 cuda -> batch[index] (Hp,Wp,8) bf16."""
+    """img (3,H0,W0) f32 cuda -> batch[index] (Hp,Wp,8) bf16 | fp16 (the batch tensor's type)."""
     _need_cuda(img, batch)
     assert img.dtype == torch.float32 and img.is_contiguous()
     _, hp, wp, c8 = batch.shape
@@ -508,9 +520,8 @@ def probe_mfma_bf16(shape, seconds=2.0, iters=20000, workgroups=256):
     launch = lambda: T.probe_mfma_bf16(int(shape), int(iters), operands, sink, int(workgroups))
     launch()
     torch.cuda.synchronize()
-    t0, n = time.perf_counter(), 0
-    best = 0.0
-    while time.perf_counter() - t0 < seconds:
+    t0, last = time.perf_counter(), 0.0
+    while True:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(4):
@@ -518,5 +529,6 @@ def probe_mfma_bf16(shape, seconds=2.0, iters=20000, workgroups=256):
         e1.record()
         torch.cuda.synchronize()
         last = 4 * flop / (e0.elapsed_time(e1) * 1e-3) / 1e12
-        n += 4
+        if time.perf_counter() - t0 >= seconds:
+            break
     return last        # the rate of the LAST group of launches: the settled clock, not the cold-start burst

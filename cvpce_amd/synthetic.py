@@ -21,7 +21,7 @@ def calibrate_head(model, logit_gain=8.0, logit_bias=1.0):
     return model
 
 
-def synthetic_gln(seed=0, detections_per_img=200, tanh=False, calibrate=True, residual_gain=1.0):
+def synthetic_gln(seed=0, detections_per_img=200, tanh=False, calibrate=True, residual_gain=1.0, precision='bf16'):
     """Seeded GLN (CPU tensors; call .cuda() to run).
 
     residual_gain < 1 scales the last FrozenBN of every bottleneck (the residual branch's output gain).  Plain random init
@@ -31,7 +31,7 @@ def synthetic_gln(seed=0, detections_per_img=200, tanh=False, calibrate=True, re
     state = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:
-        model = proposals.gln(pretrained_backbone=False, tanh=tanh, detections_per_img=detections_per_img)
+        model = proposals.gln(pretrained_backbone=False, tanh=tanh, detections_per_img=detections_per_img, precision=precision)
         # give the Gaussian-branch BatchNorms non-trivial running statistics
         for m in model.backbone.gaussian_layer.modules():
             if isinstance(m, torch.nn.BatchNorm2d):

@@ -26,6 +26,17 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _by_dtype(x, bf16_name, f16_name, *same):
+    """The C entry point for x's element type: bf16 (default storage) or fp16 (the detector's accuracy mode).  Every other 16-bit
+    operand of the call must have the same type -- the kernels cannot mix them."""
+    if x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f'{bf16_name}: activations must be bfloat16 or float16, got {x.dtype}')
+    for t in same:
+        if t is not None and t.dtype != x.dtype:
+            raise RuntimeError(f'{bf16_name}: operand of type {t.dtype} with {x.dtype} activations')
+    return getattr(lib, f16_name if x.dtype == torch.float16 else bf16_name)
+
+
 def _op(schema):
     def deco(fn):
         name = schema.split('(')[0]
@@ -43,9 +54,10 @@ def _conv2d_nhwc(x, weight, bias, residual, out, cout, kh, kw, stride, pad, ho, 
                  res_mode, pool, force_generic):
     n, h, w, cin = x.shape
     hr, wr = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
-    check(lib.cvpce_conv2d_nhwc_bf16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, kh, kw, stride, pad, ho, wo,
-                                     k_pad, cout_pad, act, out_f32, in_up_shift, res_mode if residual is not None else 0, hr, wr, pool,
-                                     force_generic, _stream()), 'cvpce_conv2d_nhwc_bf16')
+    fn = _by_dtype(x, 'cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16', weight, residual, None if out_f32 else out)
+    check(fn(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, kh, kw, stride, pad, ho, wo,
+             k_pad, cout_pad, act, out_f32, in_up_shift, res_mode if residual is not None else 0, hr, wr, pool,
+             force_generic, _stream()), 'cvpce_conv2d_nhwc')
 
 
 @_op('conv1x1_nhwc(Tensor x, Tensor weight, Tensor? bias, Tensor? residual, Tensor(a!) out, int cout, int stride, int ho, int wo, '
@@ -53,21 +65,24 @@ def _conv2d_nhwc(x, weight, bias, residual, out, cout, kh, kw, stride, pad, ho, 
 def _conv1x1_nhwc(x, weight, bias, residual, out, cout, stride, ho, wo, k_pad, cout_pad, relu, res_mode):
     n, h, w, cin = x.shape
     hr, wr = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
-    check(lib.cvpce_conv1x1_nhwc_bf16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, stride, ho, wo, k_pad,
-                                      cout_pad, relu, res_mode if residual is not None else 0, hr, wr, _stream()), 'cvpce_conv1x1_nhwc_bf16')
+    fn = _by_dtype(x, 'cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16', weight, residual, out)
+    check(fn(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, stride, ho, wo, k_pad,
+             cout_pad, relu, res_mode if residual is not None else 0, hr, wr, _stream()), 'cvpce_conv1x1_nhwc')
 
 
 @_op('conv3x3_halo(Tensor x, Tensor weight, Tensor? bias, Tensor(a!) out, int cout, int k_pad, int cout_pad, int relu, int pool) -> ()')
 def _conv3x3_halo(x, weight, bias, out, cout, k_pad, cout_pad, relu, pool):
     n, h, w, cin = x.shape
-    check(lib.cvpce_conv3x3_halo(_p(x), _p(weight), _p(bias), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, pool, _stream()),
-          'cvpce_conv3x3_halo')
+    fn = _by_dtype(x, 'cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16', weight, out)
+    check(fn(_p(x), _p(weight), _p(bias), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, pool, _stream()), 'cvpce_conv3x3_halo')
 
 
 @_op('conv3x3_halo_mac(Tensor x, Tensor weight, Tensor? bias, Tensor(a!)? out, Tensor(b!) mac, int mac_off, int cout, int k_pad, '
      'int cout_pad, int pool) -> ()')
 def _conv3x3_halo_mac(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, pool):
     n, h, w, cin = x.shape
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+        raise RuntimeError('cvpce_conv3x3_halo_mac: bf16 only (the embedder has no fp16 mode)')
     check(lib.cvpce_conv3x3_halo_mac(_p(x), _p(weight), _p(bias), _p(out), _p(mac), mac.shape[1], mac_off, n, h, w, cin, cout, k_pad,
                                      cout_pad, pool, _stream()), 'cvpce_conv3x3_halo_mac')
 
@@ -76,31 +91,36 @@ def _conv3x3_halo_mac(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad,
      'int cout_pad, int relu) -> ()')
 def _conv3x3_halo_masked(x, weight, bias, mask, tile_map, out, cout, k_pad, cout_pad, relu):
     n, h, w, cin = x.shape
-    check(lib.cvpce_conv3x3_halo_masked(_p(x), _p(weight), _p(bias), _p(mask), _p(tile_map), tile_map.numel() if tile_map is not None else 0,
-                                        _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, _stream()), 'cvpce_conv3x3_halo_masked')
+    fn = _by_dtype(x, 'cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16', weight, out)
+    check(fn(_p(x), _p(weight), _p(bias), _p(mask), _p(tile_map), tile_map.numel() if tile_map is not None else 0,
+             _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, _stream()), 'cvpce_conv3x3_halo_masked')
 
 
 @_op('vgg_stem_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out) -> ()')
 def _vgg_stem_fused(x, w1, b1, w2, b2, out):
     n, h, w, c = x.shape
+    if x.dtype != torch.bfloat16 or w1.dtype != torch.bfloat16 or w2.dtype != torch.bfloat16:
+        raise RuntimeError('cvpce_vgg_stem_fused: bf16 only (the embedder has no fp16 mode)')
     check(lib.cvpce_vgg_stem_fused(_p(x), c, _p(w1), _p(b1), _p(w2), _p(b2), _p(out), n, h, w, _stream()), 'cvpce_vgg_stem_fused')
 
 
 @_op('gln_stem_fused(Tensor x, Tensor w_frag, Tensor bias, Tensor(a!) out) -> ()')
 def _gln_stem_fused(x, w_frag, bias, out):
     n, h, w, c = x.shape
-    check(lib.cvpce_gln_stem_fused(_p(x), _p(w_frag), _p(bias), _p(out), n, h, w, _stream()), 'cvpce_gln_stem_fused')
+    fn = _by_dtype(x, 'cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16', w_frag, out)
+    check(fn(_p(x), _p(w_frag), _p(bias), _p(out), n, h, w, _stream()), 'cvpce_gln_stem_fused')
 
 
 @_op('maxpool2d_nhwc(Tensor x, Tensor(a!) out, int k, int stride, int pad) -> ()')
 def _maxpool2d_nhwc(x, out, k, stride, pad):
     n, h, w, c = x.shape
-    check(lib.cvpce_maxpool2d_nhwc_bf16(_p(x), _p(out), n, h, w, c, k, stride, pad, out.shape[1], out.shape[2], _stream()), 'maxpool')
+    fn = _by_dtype(x, 'cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16', out)
+    check(fn(_p(x), _p(out), n, h, w, c, k, stride, pad, out.shape[1], out.shape[2], _stream()), 'maxpool')
 
 
 @_op('relu(Tensor x, Tensor(a!) out) -> ()')
 def _relu(x, out):
-    check(lib.cvpce_relu_bf16(_p(x), _p(out), x.numel(), _stream()), 'relu')
+    check(_by_dtype(x, 'cvpce_relu_bf16', 'cvpce_relu_f16', out)(_p(x), _p(out), x.numel(), _stream()), 'relu')
 
 
 @_op('global_max_nhwc(Tensor x, Tensor(a!) out, int out_off) -> ()')
@@ -117,8 +137,9 @@ def _l2_normalize(x, out, out_bf16, eps):
 @_op('gln_transform(Tensor img, Tensor(a!) batch, int index, int h, int w, float[] mean, float[] std) -> ()')
 def _gln_transform(img, batch, index, h, w, mean, std):
     _, hp, wp, _ = batch.shape
-    check(lib.cvpce_gln_transform(_p(img), ctypes.c_void_p(batch[index].data_ptr()), img.shape[1], img.shape[2], h, w, hp, wp,
-                                  _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform')
+    fn = _by_dtype(batch, 'cvpce_gln_transform', 'cvpce_gln_transform_f16')
+    check(fn(_p(img), ctypes.c_void_p(batch[index].data_ptr()), img.shape[1], img.shape[2], h, w, hp, wp,
+             _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform')
 
 
 @_op('crop_resize(Tensor img, Tensor boxes, Tensor? count, Tensor(a!) out, int size, int mode, float[]? mean, float[]? std) -> ()')

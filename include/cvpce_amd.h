@@ -164,6 +164,35 @@ int cvpce_match_topk(const void* queries, const void* gallery, const float* q_no
                      int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
                      long long* out_idx, float* out_dist, void* stream);
 
+/* ---- fp16 twins: the detector's opt-in accuracy mode ------------------------------------------------------------------
+ * `gln(..., precision='fp16')` / `GaussianLayerNetwork.set_precision('fp16')` stores the detector's weights and inter-layer
+ * activations as IEEE fp16 instead of bf16 (10 instead of 7 mantissa bits; v_mfma_f32_*_f16 runs at the bf16 rate).  Each
+ * function below has exactly the contract of the function it is named after (same layouts, same epilogues, fp32
+ * accumulation and fp32 head / gaussian outputs), with every "bf16" operand read as fp16; stores saturate at +-65504.
+ * Reference semantics are unchanged: nn.Conv2d / FrozenBatchNorm2d / MaxPool2d / F.relu of torchvision's RetinaNet as built by
+ * cvpce/models/proposals.py:109-139,162-168. */
+int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const float* bias, const void* res, void* out,
+                          int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
+                          int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
+int cvpce_conv1x1_nhwc_f16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H,
+                           int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad, int relu,
+                           int res_mode, int Hr, int Wr, void* stream);
+int cvpce_gln_stem_fused_f16(const void* in_nhwc8, const void* w_frag, const float* bias, void* out, int N, int H, int W,
+                             void* stream);
+int cvpce_conv3x3_halo_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                           int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+int cvpce_conv3x3_halo_wide_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                                int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+int cvpce_conv3x3_halo_masked_f16(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                  const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
+                                  int Cout_pad, int relu, void* stream);
+int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
+                             int Ho, int Wo, void* stream);
+int cvpce_relu_f16(const void* in, void* out, long long n, void* stream);
+int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
+                            const float* mean3, const float* std3, void* stream);
+
 /* Calibration probe (not on the hot path; bench.py `measured_peaks`): a bare bf16 MFMA loop on register operands --
  * shape 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16; `workgroups` x 4 waves (one per SIMD) each issue
  * iters x 16 MFMAs on 4 x 4 independent accumulators.  operands: >= 128 KiB of random bf16; sink: workgroups * 256 floats.

@@ -100,61 +100,26 @@ def emulated_detect(img, sd, dpi):
 
 
 @torch.no_grad()
-def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
-        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None):
-    from cvpce_amd import ops, production, synthetic, datautils
-    from oracle import gln as og, crop as ocrop, match as omatch
-    log = log or (lambda *a: None)
-    dev = torch.device('cuda:0')
-    t_start = time.perf_counter()
-    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain)
-    enc = synthetic.synthetic_macvgg(seed=1)
-    det_sd = {k_: v.clone() for k_, v in det.state_dict().items()}
-    enc_sd = {k_: v.clone() for k_, v in enc.state_dict().items()}
-    det, enc = det.to(dev), enc.to(dev)
-    galleries = tuple(sorted(int(g) for g in galleries))
-    gmax, gmin = galleries[-1], galleries[0]
-    products = synthetic.product_images(gmax, seed=200 + seed)
-    gal_tanh = products * 2 - 1                                          # gallery tensors live in [-1, 1] (datautils.py:446)
-    hip_gal = torch.cat([enc(gal_tanh[i:i + 128].to(dev)) for i in range(0, gmax, 128)])
-    log(f'[accuracy] {gmax} products, HIP gallery embedded ({time.perf_counter() - t_start:.1f} s)')
-    t = time.perf_counter()
-    orc_gal = oracle_embed(gal_tanh, enc_sd, oracle_device)
-    log(f'[accuracy] oracle gallery embedded on {oracle_device} ({time.perf_counter() - t:.1f} s)')
-    report = {'n_images': n_images, 'image_size': image_size, 'detections_per_img': dpi, 'oracle_device_embedder': oracle_device,
-              'detector_residual_gain': residual_gain,
-              'data': 'structured shelves (cvpce_amd.synthetic.structured_shelf), seeded random-init weights'}
-    if oracle_device != 'cpu':                                           # the GPU run of the oracle code vs its CPU run
-        chk = oracle_embed(gal_tanh[:8], enc_sd, 'cpu')
-        report['oracle_cuda_vs_cpu_max_abs'] = float((chk - orc_gal[:8]).abs().max())
-    gal_cos = torch.nn.functional.cosine_similarity(hip_gal.cpu(), orc_gal, dim=1)
-    report['gallery_embedding_cosine_min'] = float(gal_cos.min())
+def _ap_area(targets, preds, confs, thr=0.5):
+    """All-point AP (area under the interpolated precision / recall curve) and final recall with the SAME matching code.
+    The reference's 11-point AP (cvpce/metrics.py:66-73) samples precision at recall 1.0: it cannot exceed 10/11 = 0.909
+    unless EVERY target is found, so it saturates as a reproduction measure; the area form does not."""
+    from cvpce_amd import metrics
+    r = metrics.calculate_metrics(targets, preds, confs, iou_thresholds=(thr,))[thr]['raw']
+    p, rc = r['p'], r['r']
+    if not len(p):
+        return 0.0, 0.0
+    env = torch.flip(torch.cummax(torch.flip(p, (0,)), 0).values, (0,))           # precision envelope
+    prev = torch.cat((torch.zeros(1), rc[:-1]))
+    return float(((rc - prev) * env).sum()), float(rc[-1])
 
-    # ---- images: HIP pipeline (product defaults) and the oracle detector ----------------------------------------------
-    shelves = [synthetic.structured_shelf(1000 * seed + i, image_size, image_size, products, pool=range(gmin)) for i in range(n_images)]
-    clf = {(g, md): production.Classifier.from_embedding(enc, hip_gal[:g], list(range(g)), device=dev, emb_device=dev, k=min(k, g),
-                                                         match_dtype=torch.bfloat16 if md == 'bf16' else torch.float32)
-           for g in galleries for md in match_dtypes}
-    first = clf[(galleries[0], match_dtypes[0])]
-    pipe = production.BatchedPipeline(det, first, 0.5)
-    hip = []
-    for s in range(0, n_images, images_per_batch):
-        imgs = [sh[0].to(dev) for sh in shelves[s:s + images_per_batch]]
-        out = pipe.run(imgs)
-        emb, off = out['embeddings'], 0
-        for i in range(len(imgs)):
-            c, dc = int(out['count'][i]), int(out['det_count'][i])
-            e = emb[off:off + c]; off += c
-            idx = {key: (c_.match(e).cpu() if c else torch.empty(0, c_.k, dtype=torch.int64)) for key, c_ in clf.items()}
-            hip.append({'boxes': out['boxes'][i, :dc].cpu(), 'scores': out['scores'][i, :dc].cpu(), 'conf': c, 'idx': idx})
-    t = time.perf_counter()
-    orc = [og.gln_forward([sh[0]], det_sd, detections_per_img=dpi)[0] for sh in shelves]
-    log(f'[accuracy] oracle detector on {n_images} images ({time.perf_counter() - t:.1f} s)')
 
-    # ---- detection -----------------------------------------------------------------------------------------------------
+def _detection_report(hip, orc, shelves):
     hb, hs = [h['boxes'] for h in hip], [h['scores'] for h in hip]
     ob, os_ = [o['boxes'] for o in orc], [o['scores'] for o in orc]
     vs = _ap(ob, hb, hs)
+    area50, recall50 = _ap_area(ob, hb, hs, 0.5)
+    area75, _ = _ap_area(ob, hb, hs, 0.75)
     pg = [o['boxes'][o['scores'] > 0.5] for o in orc]
     gt = [sh[1] for sh in shelves]
     found, total, dscore, dbox = 0, 0, [], []
@@ -169,9 +134,12 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
     dbox = torch.cat(dbox) if dbox else torch.zeros(1)
     a_h, a_o = _ap(pg, hb, hs), _ap(pg, ob, os_)
     g_h, g_o = _ap(gt, hb, hs), _ap(gt, ob, os_)
-    report['detection'] = {
+    return {
         'ap50_vs_oracle': vs[0.5]['ap'], 'ap75_vs_oracle': vs[0.75]['ap'], 'ar300_vs_oracle': vs[0.5]['ar_300'],
         'ar300_iou75_vs_oracle': vs[0.75]['ar_300'],
+        'ap50_area_vs_oracle': area50, 'ap75_area_vs_oracle': area75, 'recall50_vs_oracle': recall50,
+        'ap_note': 'ap50/ap75 = the reference\'s 11-point AP (cvpce/metrics.py:66-73): capped at 10/11 = 0.909 unless recall reaches 1.0; '
+                   'ap*_area = all-point area under the same precision/recall curve',
         'frac_oracle_boxes_iou90': found / max(1, total), 'oracle_boxes': total,
         'paired_abs_score_diff_max': float(dscore.max()), 'paired_abs_score_diff_mean': float(dscore.mean()),
         'paired_box_diff_px_max': float(dbox.max()), 'paired_box_diff_px_mean': float(dbox.mean()),
@@ -183,39 +151,114 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
                       'delta_ar300_pt': 100 * (a_h[0.5]['ar_300'] - a_o[0.5]['ar_300'])},
         'gt': {'ap50_hip': g_h[0.5]['ap'], 'ap50_oracle': g_o[0.5]['ap'], 'delta_pt': 100 * (g_h[0.5]['ap'] - g_o[0.5]['ap'])}}
 
-    if control_images:
-        t = time.perf_counter()
-        m = min(control_images, n_images)
-        emu = [emulated_detect(sh[0], det_sd, dpi) for sh in shelves[:m]]
-        eb, es = [e['boxes'] for e in emu], [e['scores'] for e in emu]
-        e_vs_o, h_vs_e, h_vs_o = _ap(ob[:m], eb, es), _ap(eb, hb[:m], hs[:m]), _ap(ob[:m], hb[:m], hs[:m])
-        frac = lambda a, b: sum(len(pair_boxes(x, y)) for x, y in zip(a, b)) / max(1, sum(len(y) for y in b))
-        report['detection']['control_bf16_emulation'] = {
-            'images': m,
-            'what': 'oracle/bf16_model.py = the fp32 oracle graph with the HIP schedule\'s bf16 rounding points, on the CPU',
-            'emulation_vs_oracle': {'ap50': e_vs_o[0.5]['ap'], 'ar300': e_vs_o[0.5]['ar_300'], 'frac_boxes_iou90': frac(eb, ob[:m])},
-            'hip_vs_oracle_same_images': {'ap50': h_vs_o[0.5]['ap'], 'ar300': h_vs_o[0.5]['ar_300'], 'frac_boxes_iou90': frac(hb[:m], ob[:m])},
-            'hip_vs_emulation': {'ap50': h_vs_e[0.5]['ap'], 'ar300': h_vs_e[0.5]['ar_300'], 'frac_boxes_iou90': frac(hb[:m], eb)}}
-        log(f'[accuracy] bf16-emulation control on {m} images ({time.perf_counter() - t:.1f} s)')
 
-    # ---- matching: paired detections ------------------------------------------------------------------------------------
-    gen = torch.Generator().manual_seed(77 + seed)
-    allp = []
-    for n, (h, o) in enumerate(zip(hip, orc)):
-        oc = o['boxes'][o['scores'] > 0.5]
-        for i, j in pair_boxes(h['boxes'][:h['conf']], oc):
-            lb = oc[j].to(torch.long)
-            if lb[2] > lb[0] and lb[3] > lb[1]:
-                allp.append((n, i, j))
-    sel = [allp[i] for i in torch.randperm(len(allp), generator=gen)[:queries].tolist()]
+@torch.no_grad()
+def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
+        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None, precisions=('bf16',)):
+    """precisions: detector storage modes to measure ('bf16' = the default schedule, 'fp16' = the accuracy mode); the oracle
+    side is computed once.  The report's top-level `detection` / `matching` are those of precisions[0]; every mode's figures
+    are under `by_precision`."""
+    from cvpce_amd import ops, production, synthetic, datautils
+    from oracle import gln as og, crop as ocrop, match as omatch
+    log = log or (lambda *a: None)
+    dev = torch.device('cuda:0')
+    t_start = time.perf_counter()
+    det0 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain)
+    enc = synthetic.synthetic_macvgg(seed=1)
+    det_sd = {k_: v.clone() for k_, v in det0.state_dict().items()}
+    enc_sd = {k_: v.clone() for k_, v in enc.state_dict().items()}
+    enc = enc.to(dev)
+    galleries = tuple(sorted(int(g) for g in galleries))
+    gmax, gmin = galleries[-1], galleries[0]
+    products = synthetic.product_images(gmax, seed=200 + seed)
+    gal_tanh = products * 2 - 1                                          # gallery tensors live in [-1, 1] (datautils.py:446)
+    hip_gal = torch.cat([enc(gal_tanh[i:i + 128].to(dev)) for i in range(0, gmax, 128)])
+    log(f'[accuracy] {gmax} products, HIP gallery embedded ({time.perf_counter() - t_start:.1f} s)')
     t = time.perf_counter()
-    crops = []
-    for n, i, j in sel:
-        oc = orc[n]['boxes'][orc[n]['scores'] > 0.5]
-        crops.append(ocrop.crop_boxes(shelves[n][0], oc[j:j + 1])[0])
-    q_orc = oracle_embed(ocrop.scale_to_tanh(torch.stack(crops)), enc_sd, oracle_device) if crops else torch.empty(0, 1024)
-    log(f'[accuracy] oracle crop+embed of {len(sel)} paired detections ({time.perf_counter() - t:.1f} s)')
-    # ---- matching: ground-truth boxes (classification_eval.py:19-42 flow) ------------------------------------------------
+    orc_gal = oracle_embed(gal_tanh, enc_sd, oracle_device)
+    log(f'[accuracy] oracle gallery embedded on {oracle_device} ({time.perf_counter() - t:.1f} s)')
+    report = {'n_images': n_images, 'image_size': image_size, 'detections_per_img': dpi, 'oracle_device_embedder': oracle_device,
+              'detector_residual_gain': residual_gain, 'detector_precisions': list(precisions),
+              'data': 'structured shelves (cvpce_amd.synthetic.structured_shelf), seeded random-init weights'}
+    if oracle_device != 'cpu':                                           # the GPU run of the oracle code vs its CPU run
+        chk = oracle_embed(gal_tanh[:8], enc_sd, 'cpu')
+        report['oracle_cuda_vs_cpu_max_abs'] = float((chk - orc_gal[:8]).abs().max())
+    gal_cos = torch.nn.functional.cosine_similarity(hip_gal.cpu(), orc_gal, dim=1)
+    report['gallery_embedding_cosine_min'] = float(gal_cos.min())
+
+    shelves = [synthetic.structured_shelf(1000 * seed + i, image_size, image_size, products, pool=range(gmin)) for i in range(n_images)]
+    clf = {(g, md): production.Classifier.from_embedding(enc, hip_gal[:g], list(range(g)), device=dev, emb_device=dev, k=min(k, g),
+                                                         match_dtype=torch.bfloat16 if md == 'bf16' else torch.float32)
+           for g in galleries for md in match_dtypes}
+    first = clf[(galleries[0], match_dtypes[0])]
+    t = time.perf_counter()
+    orc = [og.gln_forward([sh[0]], det_sd, detections_per_img=dpi)[0] for sh in shelves]
+    log(f'[accuracy] oracle detector on {n_images} images ({time.perf_counter() - t:.1f} s)')
+    ob = [o['boxes'] for o in orc]
+
+    # ---- per detector precision: the HIP pipeline (product defaults), detection agreement, paired-detection matching --------------
+    report['by_precision'] = {}
+    emu = None
+    for prec in precisions:
+        det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain, precision=prec).to(dev)
+        pipe = production.BatchedPipeline(det, first, 0.5)
+        hip = []
+        for s in range(0, n_images, images_per_batch):
+            imgs = [sh[0].to(dev) for sh in shelves[s:s + images_per_batch]]
+            out = pipe.run(imgs)
+            emb, off = out['embeddings'], 0
+            for i in range(len(imgs)):
+                c, dc = int(out['count'][i]), int(out['det_count'][i])
+                e = emb[off:off + c]; off += c
+                idx = {key: (c_.match(e).cpu() if c else torch.empty(0, c_.k, dtype=torch.int64)) for key, c_ in clf.items()}
+                hip.append({'boxes': out['boxes'][i, :dc].cpu(), 'scores': out['scores'][i, :dc].cpu(), 'conf': c, 'idx': idx})
+        del pipe, det
+        rp = {'detection': _detection_report(hip, orc, shelves), 'matching_pairs': {}}
+        hb, hs = [h['boxes'] for h in hip], [h['scores'] for h in hip]
+        if control_images and prec == 'bf16':
+            t = time.perf_counter()
+            m = min(control_images, n_images)
+            emu = emu or [emulated_detect(sh[0], det_sd, dpi) for sh in shelves[:m]]
+            eb, es = [e['boxes'] for e in emu], [e['scores'] for e in emu]
+            e_vs_o, h_vs_e, h_vs_o = _ap(ob[:m], eb, es), _ap(eb, hb[:m], hs[:m]), _ap(ob[:m], hb[:m], hs[:m])
+            frac = lambda a, b: sum(len(pair_boxes(x, y)) for x, y in zip(a, b)) / max(1, sum(len(y) for y in b))
+            rp['detection']['control_bf16_emulation'] = {
+                'images': m,
+                'what': 'oracle/bf16_model.py = the fp32 oracle graph with the HIP schedule\'s bf16 rounding points, on the CPU',
+                'emulation_vs_oracle': {'ap50': e_vs_o[0.5]['ap'], 'ar300': e_vs_o[0.5]['ar_300'], 'frac_boxes_iou90': frac(eb, ob[:m])},
+                'hip_vs_oracle_same_images': {'ap50': h_vs_o[0.5]['ap'], 'ar300': h_vs_o[0.5]['ar_300'], 'frac_boxes_iou90': frac(hb[:m], ob[:m])},
+                'hip_vs_emulation': {'ap50': h_vs_e[0.5]['ap'], 'ar300': h_vs_e[0.5]['ar_300'], 'frac_boxes_iou90': frac(hb[:m], eb)}}
+            log(f'[accuracy] bf16-emulation control on {m} images ({time.perf_counter() - t:.1f} s)')
+        # paired detections: HIP box <-> oracle confident box, the index each path matched
+        gen = torch.Generator().manual_seed(77 + seed)
+        allp = []
+        for n, (h, o) in enumerate(zip(hip, orc)):
+            oc = o['boxes'][o['scores'] > 0.5]
+            for i, j in pair_boxes(h['boxes'][:h['conf']], oc):
+                lb = oc[j].to(torch.long)
+                if lb[2] > lb[0] and lb[3] > lb[1]:
+                    allp.append((n, i, j))
+        sel = [allp[i] for i in torch.randperm(len(allp), generator=gen)[:queries].tolist()]
+        t = time.perf_counter()
+        crops = []
+        for n, i, j in sel:
+            oc = orc[n]['boxes'][orc[n]['scores'] > 0.5]
+            crops.append(ocrop.crop_boxes(shelves[n][0], oc[j:j + 1])[0])
+        q_orc = oracle_embed(ocrop.scale_to_tanh(torch.stack(crops)), enc_sd, oracle_device) if crops else torch.empty(0, 1024)
+        log(f'[accuracy] {prec}: oracle crop+embed of {len(sel)} paired detections ({time.perf_counter() - t:.1f} s)')
+        for g in galleries:
+            o_idx = omatch.nearest_neighbors(orc_gal[:g], q_orc, min(k, g)) if len(q_orc) else torch.empty(0, k, dtype=torch.int64)
+            for md in match_dtypes:
+                h_idx = torch.stack([hip[n]['idx'][(g, md)][i] for n, i, j in sel]) if sel else torch.empty(0, k, dtype=torch.int64)
+                top1 = (h_idx[:, 0] == o_idx[:, 0]).float().mean().item() if len(sel) else None
+                topk = (h_idx == o_idx[:, :1]).any(dim=1).float().mean().item() if len(sel) else None
+                rp['matching_pairs'][f'G{g}_{md}'] = {'n': len(sel), 'top1_agree': top1, f'top{k}_contains_oracle_top1': topk}
+        report['by_precision'][prec] = rp
+    p0 = report['by_precision'][precisions[0]]
+    report['detection'] = p0['detection']
+
+    # ---- matching: ground-truth boxes (classification_eval.py:19-42 flow; independent of the detector) -------------------
+    gen = torch.Generator().manual_seed(78 + seed)
     allg = [(n, b) for n, sh in enumerate(shelves) for b in range(len(sh[1]))]
     selg = [allg[i] for i in torch.randperm(len(allg), generator=gen)[:queries].tolist()]
     t = time.perf_counter()
@@ -239,20 +282,16 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
     report['embedding_cosine_min_gt_crops'] = float(emb_cos.min())
     report['matching'] = {}
     for g in galleries:
-        o_idx = omatch.nearest_neighbors(orc_gal[:g], q_orc, min(k, g)) if len(q_orc) else torch.empty(0, k, dtype=torch.int64)
         og_idx = omatch.nearest_neighbors(orc_gal[:g], g_orc, min(k, g)) if len(g_orc) else torch.empty(0, k, dtype=torch.int64)
         d = omatch.cosine_distance_matrix(orc_gal[:g], g_orc).sort(dim=1).values if len(g_orc) else torch.zeros(0, 2)
         for md in match_dtypes:
-            h_idx = torch.stack([hip[n]['idx'][(g, md)][i] for n, i, j in sel]) if sel else torch.empty(0, k, dtype=torch.int64)
             hg_idx = clf[(g, md)].match(g_hip).cpu() if len(selg) else torch.empty(0, k, dtype=torch.int64)
-            top1 = (h_idx[:, 0] == o_idx[:, 0]).float().mean().item() if len(sel) else None
-            topk = (h_idx == o_idx[:, :1]).any(dim=1).float().mean().item() if len(sel) else None
             acc_h = (hg_idx[:, 0] == g_true).float().mean().item() if len(selg) else None
             acc_o = (og_idx[:, 0] == g_true).float().mean().item() if len(selg) else None
             agree = (hg_idx[:, 0] == og_idx[:, 0])
             flips = ~agree
             report['matching'][f'G{g}_{md}'] = {
-                'pairs': {'n': len(sel), 'top1_agree': top1, f'top{k}_contains_oracle_top1': topk},
+                'pairs': p0['matching_pairs'][f'G{g}_{md}'],
                 'gt_boxes': {'n': len(selg), 'acc_hip': acc_h, 'acc_oracle': acc_o,
                              'delta_pt': 100 * (acc_h - acc_o) if selg else None,
                              'top1_agree': agree.float().mean().item() if len(selg) else None,
@@ -263,16 +302,26 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
 
 
 def summary(report):
-    """The handful of figures bench.py puts into its `parity` object."""
-    d = report['detection']
-    out = {'images': report['n_images'], 'ap50_vs_oracle': round(d['ap50_vs_oracle'], 4), 'ar300_vs_oracle': round(d['ar300_vs_oracle'], 4),
-           'frac_oracle_boxes_iou90': round(d['frac_oracle_boxes_iou90'], 4),
-           'map_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_pt'], 3), 'ar300_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_ar300_pt'], 3)}
+    """The handful of figures bench.py puts into its `parity` object: top level = the first (default, bf16) detector precision,
+    `by_precision` = the detector agreement of every measured mode."""
+    def det(d):
+        return {'ap50_vs_oracle': round(d['ap50_vs_oracle'], 4), 'ap50_area_vs_oracle': round(d['ap50_area_vs_oracle'], 4),
+                'ar300_vs_oracle': round(d['ar300_vs_oracle'], 4), 'frac_oracle_boxes_iou90': round(d['frac_oracle_boxes_iou90'], 4),
+                'paired_box_diff_px_mean': round(d['paired_box_diff_px_mean'], 4),
+                'map_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_pt'], 3), 'ar300_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_ar300_pt'], 3)}
+    out = {'images': report['n_images']}
+    out.update(det(report['detection']))
     for key, m in report['matching'].items():
         out[key] = {'pairs': m['pairs']['n'], 'top1_agree': None if m['pairs']['top1_agree'] is None else round(m['pairs']['top1_agree'], 4),
                     'gt_crops': m['gt_boxes']['n'],
                     'gt_top1_agree': None if m['gt_boxes']['top1_agree'] is None else round(m['gt_boxes']['top1_agree'], 4),
                     'top1_acc_delta_pt': None if m['gt_boxes']['delta_pt'] is None else round(m['gt_boxes']['delta_pt'], 3)}
+    out['by_precision'] = {}
+    for prec, rp in report.get('by_precision', {}).items():
+        e = det(rp['detection'])
+        for key, m in rp['matching_pairs'].items():
+            e[f'pairs_top1_agree_{key}'] = None if m['top1_agree'] is None else round(m['top1_agree'], 4)
+        out['by_precision'][prec] = e
     return out
 
 
@@ -286,11 +335,13 @@ def main():
     ap.add_argument('--oracle-device', default='cpu', choices=['cpu', 'cuda'])
     ap.add_argument('--control-images', type=int, default=8, help='images of the bf16-emulation control (oracle/bf16_model.py)')
     ap.add_argument('--residual-gain', type=float, default=1.0, help='synthetic_gln residual_gain (conditioning of the random detector)')
+    ap.add_argument('--precisions', default='bf16,fp16', help="detector storage modes to measure (first = the report's top level)")
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     rep = run(a.images, a.image_size, tuple(int(g) for g in a.galleries.split(',')), a.detections_per_img, a.queries, a.oracle_device,
-              control_images=a.control_images, residual_gain=a.residual_gain, log=lambda *x: print(*x, flush=True))
+              control_images=a.control_images, residual_gain=a.residual_gain, log=lambda *x: print(*x, flush=True),
+              precisions=tuple(a.precisions.split(',')))
     text = json.dumps(rep, indent=1)
     print(text)
     if a.out:
