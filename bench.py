@@ -47,6 +47,10 @@ def parse():
     ap.add_argument('--gallery', type=int, default=3200)
     ap.add_argument('--detections-per-img', type=int, default=None, help='default 200 (pipeline, cli/eval.py:50) / 1000 (detector)')
     ap.add_argument('--match-dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--detector-precision', default='bf16', choices=['bf16', 'fp16'],
+                    help="storage type of the detector's weights / activations: bf16 (default, what BASELINE's configs name) or the fp16 accuracy mode")
+    ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; value = the median window')
+    ap.add_argument('--no-workloads', action='store_true', help='skip the configs[1] / configs[3] figures appended to the pipeline line')
     ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -199,6 +203,31 @@ def gather_digests(local, world):
     return merged
 
 
+def timed_windows(step, steps, windows, dev):
+    """`windows` back-to-back timed regions of EXACTLY `steps` calls of `step()`, each bracketed by barrier +
+    torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  -> (median seconds, [seconds per window]).
+    One window of ~1 s decides little on a power-limited part with +-3 % box-to-box spread; the line reports the median
+    and the spread."""
+    from cvpce_amd import dist as cdist
+    secs = []
+    for _ in range(max(1, windows)):
+        torch.cuda.synchronize()
+        cdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        cdist.barrier()
+        secs.append(cdist.max_over_ranks(time.perf_counter() - t0, dev))
+    return sorted(secs)[len(secs) // 2], secs
+
+
+def window_stats(secs, steps):
+    ms = [round(t / steps * 1e3, 3) for t in secs]
+    return {'n': len(ms), 'steps_each': steps, 'ms_per_step': ms, 'min': min(ms), 'max': max(ms), 'value': 'median window'}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # workload: full pipeline (the headline metric)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -240,7 +269,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     from cvpce_amd import dist as cdist, ops, production, synthetic
     ipg = args.images_per_gpu or 8
     dpi = args.detections_per_img or 200
-    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=args.detector_precision)
     enc = synthetic.synthetic_macvgg(seed=1)
     det_sd = {k: v.clone() for k, v in det.state_dict().items()} if rank == 0 else None
     enc_sd = {k: v.clone() for k, v in enc.state_dict().items()} if rank == 0 else None
@@ -268,18 +297,15 @@ def run_pipeline(args, rank, local_rank, world, dev):
     images = [h.to(dev) for h in host_images]
     torch.cuda.synchronize()
 
-    out = None
+    outs = [None]
+
+    def step():
+        outs[0] = pipe.run(images)
+
     for _ in range(args.warmup):
-        out = pipe.run(images)
-    torch.cuda.synchronize()
-    cdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = pipe.run(images)
-    torch.cuda.synchronize()
-    cdist.barrier()
-    elapsed = cdist.max_over_ranks(time.perf_counter() - t0, dev)
+        step()
+    elapsed, window_secs = timed_windows(step, args.steps, args.windows, dev)
+    out = outs[0]
     proposals = float(sum(out['counts_host'])) / max(1, len(images))
 
     verify = None
@@ -328,15 +354,24 @@ def run_pipeline(args, rank, local_rank, world, dev):
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         import accuracy                                           # tests/accuracy.py: the oracle as CHECKER (never timed, never shipped)
         torch.set_num_threads(min(16, os.cpu_count() or 1))
+        precs = (args.detector_precision,) + tuple(p for p in ('bf16', 'fp16') if p != args.detector_precision)
         rep = accuracy.run(n_images=4, image_size=args.image_size, galleries=(256,), dpi=dpi, queries=64, oracle_device='cpu',
-                           match_dtypes=(args.match_dtype,), images_per_batch=4)
+                           match_dtypes=(args.match_dtype,), images_per_batch=4, precisions=precs)
         parity = accuracy.summary(rep)
-        parity['sample'] = ('4 structured shelf images through the whole HIP pipeline (bench defaults) vs the whole fp32 CPU oracle; '
+        parity['sample'] = ('4 structured shelf images through the whole HIP pipeline vs the whole fp32 CPU oracle; top level = the detector '
+                            f'precision of this run ({args.detector_precision}), by_precision = both detector modes (bf16 default, fp16 accuracy mode); '
                             '64 paired detections + 64 ground-truth crops vs a 256-product gallery; full-size figures (32 images, '
-                            'G = 1000 / 3200): profiles/r02_accuracy.json')
+                            'G = 1000 / 3200): profiles/r03_accuracy.json')
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
+    workloads = None
+    if not args.no_workloads and rank == 0:
+        # BASELINE configs[1] and configs[3] on this same box (a few hundred ms of GPU time): the driver only runs the default line
+        del pipe, out, outs
+        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision)
+        workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
+                     'match_stress_configs3': match_stress_cases(dev, 200, 3)}
 
     if rank != 0:
         return None
@@ -346,17 +381,19 @@ def run_pipeline(args, rank, local_rank, world, dev):
         'value': round(total_images / elapsed, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'windows': window_stats(window_secs, args.steps),
         'config': {'workload': f'full production path: {ipg} shelf images/GPU of 3x{args.image_size}x{args.image_size} '
                                f'(SKU-110K shape) -> GLN detect (800x800 internal, detections_per_img={dpi}, conf>0.5) -> RoI crop 256x256 '
                                f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
                    'images_per_gpu': ipg, 'global_images': world * ipg, 'proposals_per_image': proposals, 'gallery': args.gallery,
-                   'match_dtype': args.match_dtype, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
+                   'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
                    'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
                    'gallery_build_s': round(t_gallery, 3)},
     }
     if h2d is not None:
         line.update(h2d)
-    for key, val in (('roofline', roofline), ('measured_peaks', peaks), ('parity', parity), ('cpu_baseline', cpu), ('verify', verify)):
+    for key, val in (('roofline', roofline), ('measured_peaks', peaks), ('parity', parity), ('cpu_baseline', cpu), ('workloads', workloads),
+                     ('verify', verify)):
         if val is not None:
             line[key] = val
     return line
@@ -365,51 +402,64 @@ def run_pipeline(args, rank, local_rank, world, dev):
 # ---------------------------------------------------------------------------------------------------------------------
 # workload: detector only (BASELINE configs[1])
 # ---------------------------------------------------------------------------------------------------------------------
+def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16', ids=None, windows=1, want_profile=False):
+    """`ipg` shelf images through the GLN detector only (transform, ResNet-50 + FPN, Gaussian branch, heads, top-k / NMS), the
+    graph-replayed schedule `GLNEngine.detect` runs in production.  -> dict of figures (+ the engine / model for the caller)."""
+    from cvpce_amd import ops, synthetic
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=precision).to(dev)
+    eng = det.engine()
+    ids = list(range(ipg)) if ids is None else ids
+    images = [synthetic.shelf_image(g, image_size, image_size).to(dev) for g in ids]
+    outs = [None]
+
+    def step():
+        outs[0] = eng.detect(images, 1, dpi)
+
+    for _ in range(warmup):
+        step()
+    elapsed, secs = timed_windows(step, steps, windows, dev)
+    ms = elapsed / steps * 1e3
+    gf = 298.4 * ipg
+    res = {'images': ipg, 'image_size': image_size, 'detections_per_img': dpi, 'precision': precision, 'ms_per_step': round(ms, 3),
+           'images_per_s': round(ipg / ms * 1e3, 1), 'kept_per_image': float(outs[0][3].float().mean()),
+           'algorithmic_gflop': round(gf, 1), 'tflops': round(gf / ms, 1), 'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+    if windows > 1:
+        res['windows'] = window_stats(secs, steps)
+    if want_profile:
+        ops.PROFILE = ops.ConvProfile()
+        for _ in range(steps):
+            step()
+        res['_conv_summary'] = ops.PROFILE.summary()
+        ops.PROFILE = None
+    res['_elapsed'] = elapsed
+    return res
+
+
 def run_detector(args, rank, local_rank, world, dev):
-    from cvpce_amd import dist as cdist, ops, synthetic
+    from cvpce_amd import dist as cdist, synthetic
     ipg = args.images_per_gpu or 4
     dpi = args.detections_per_img or 1000
-    det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi)
-    det_sd = {k: v.clone() for k, v in det.state_dict().items()} if rank == 0 else None
-    det = det.to(dev)
-    eng = det.engine()
     ids = cdist.shard_images(world * ipg, rank, world)
-    images = [synthetic.shelf_image(g, args.image_size, args.image_size).to(dev) for g in ids]
-    torch.cuda.synchronize()
-    out = None
-    for _ in range(args.warmup):
-        out = eng.detect(images, 1, dpi)
-    torch.cuda.synchronize()
-    cdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = eng.detect(images, 1, dpi)
-    torch.cuda.synchronize()
-    cdist.barrier()
-    elapsed = cdist.max_over_ranks(time.perf_counter() - t0, dev)
-    kept = float(out[3].float().mean())
+    w = detector_workload(dev, ipg, dpi, args.image_size, args.steps, args.warmup, args.detector_precision, ids=ids, windows=args.windows,
+                          want_profile=(not args.no_roofline and rank == 0))
+    elapsed = w.pop('_elapsed')
+    summ = w.pop('_conv_summary', None)
     roofline = None
-    if not args.no_roofline and rank == 0:
-        ops.PROFILE = ops.ConvProfile()
-        for _ in range(args.steps):
-            eng.detect(images, 1, dpi)
-        summ = ops.PROFILE.summary()
-        ops.PROFILE = None
-        gf = 298.4 * ipg
-        ms = elapsed / args.steps * 1e3
-        roofline = conv_roofline(summ, {'detect': {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1), 'tflops': round(gf / ms, 1),
-                                                   'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}})
+    if summ is not None:
+        roofline = conv_roofline(summ, {'detect': {k: w[k] for k in ('ms_per_step', 'algorithmic_gflop', 'tflops', 'frac_of_mfma_peak')}})
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
+        det_sd = {k: v.clone() for k, v in synthetic.synthetic_gln(seed=0, detections_per_img=dpi).state_dict().items()}
         cpu = cpu_baseline(det_sd, None, dpi, None, args.image_size)
     if rank != 0:
         return None
     line = {'metric': 'shelf images/sec, GLN detector only (convs + Gaussian head + top-k/NMS)', 'value': round(world * ipg * args.steps / elapsed, 3),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.detector_precision, 'data': 'synthetic',
+            'windows': w.get('windows'),
             'config': {'workload': f'GLN detector only: {ipg} x 3x{args.image_size}x{args.image_size} (SKU-110K shape, 800x800 internal), '
-                                   f'detections_per_img={dpi} (BASELINE configs[1])', 'images_per_gpu': ipg, 'kept_per_image': kept,
+                                   f'detections_per_img={dpi} (BASELINE configs[1])', 'images_per_gpu': ipg, 'kept_per_image': w['kept_per_image'],
+                       'detector_precision': args.detector_precision,
                        'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)', 'parallelism': f'dp{world}'}}
     if roofline is not None:
         line['roofline'] = roofline
@@ -421,17 +471,17 @@ def run_detector(args, rank, local_rank, world, dev):
 # ---------------------------------------------------------------------------------------------------------------------
 # workload: distance-GEMM stress (BASELINE configs[3])
 # ---------------------------------------------------------------------------------------------------------------------
-def run_match_stress(args, rank, local_rank, world, dev):
-    from cvpce_amd import dist as cdist, ops
+def match_stress_cases(dev, iters, warmup):
+    """BASELINE configs[3]: P queries x 10 000 gallery rows x D, bf16 distance GEMM + fused top-1, per launch (graph-replayed)."""
+    from cvpce_amd import ops
     G = 10000
     cases = []
     g = torch.Generator().manual_seed(0)
-    iters = max(20, args.steps * 10)
     for P, D in ((200, 512), (200, 1024), (1600, 512), (1600, 1024)):
         gal = torch.nn.functional.normalize(torch.randn(G, D, generator=g), dim=1).to(dev).to(torch.bfloat16)
         q = torch.nn.functional.normalize(torch.randn(P, D, generator=torch.Generator().manual_seed(1)), dim=1).to(dev).to(torch.bfloat16)
         gn, qn = ops.row_norms(gal), ops.row_norms(q)
-        for _ in range(max(3, args.warmup)):
+        for _ in range(max(3, warmup)):
             ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
         torch.cuda.synchronize()
         # the launches are replayed from a hipGraph: at ~10-50 us per launch the Python -> dispatcher -> ctypes path would
@@ -458,6 +508,12 @@ def run_match_stress(args, rank, local_rank, world, dev):
                       'bound': 'hbm' if flop / byts < MFMA_BF16_DENSE_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else 'mfma',
                       'frac_of_hbm_peak': round(byts / us / 1e3 / HBM_PEAK_GBS, 4), 'frac_of_mfma_peak': round(flop / us / 1e6 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
                       'queries_per_s': round(P / us * 1e6, 0)})
+    return cases
+
+
+def run_match_stress(args, rank, local_rank, world, dev):
+    iters = max(20, args.steps * 10)
+    cases = match_stress_cases(dev, iters, args.warmup)
     if rank != 0:
         return None
     head = cases[0]

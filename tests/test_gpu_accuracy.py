@@ -59,7 +59,7 @@ def test_fp16_accuracy_mode_closes_the_detector_gap(report):
     assert f['ap50_area_vs_oracle'] >= 0.97 and f['ar300_vs_oracle'] >= 0.985, f
     assert f['ap50_vs_oracle'] >= 0.90, f                                  # the 11-point form, at its 10/11 ceiling
     assert f['paired_box_diff_px_mean'] < 0.3 and f['paired_abs_score_diff_mean'] < 2e-4, f
-    assert abs(f['pseudo_gt']['delta_pt']) <= 2.0, f['pseudo_gt']          # bf16: ~ -10 pt
+    assert abs(f['pseudo_gt']['delta_area_pt']) <= 1.5 < abs(b['pseudo_gt']['delta_area_pt']), (f['pseudo_gt'], b['pseudo_gt'])   # full size: -0.8 vs -4.7 pt
     # and it is an improvement over the default mode on every agreement figure
     assert f['frac_oracle_boxes_iou90'] > b['frac_oracle_boxes_iou90'] + 0.03
     assert f['paired_box_diff_px_mean'] < 0.5 * b['paired_box_diff_px_mean']

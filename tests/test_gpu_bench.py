@@ -30,6 +30,12 @@ def test_pipeline_line_small(cuda):
     assert d['value_with_h2d'] > 0 and d['upload_mb_per_step'] > 0
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    assert d['windows']['n'] == 3 and len(d['windows']['ms_per_step']) == 3 and d['windows']['min'] <= d['ms_per_step'] <= d['windows']['max']
+    w = d['workloads']                                   # BASELINE configs[1] and configs[3] ride on the default (driver-run) line
+    assert w['detector_configs1']['images'] == 4 and w['detector_configs1']['detections_per_img'] == 1000 and w['detector_configs1']['ms_per_step'] > 0
+    assert {(c['P'], c['D']) for c in w['match_stress_configs3']} == {(200, 512), (200, 1024), (1600, 512), (1600, 1024)}
+    assert set(d['parity']['by_precision']) == {'bf16', 'fp16'}
+    assert d['parity']['by_precision']['fp16']['frac_oracle_boxes_iou90'] >= d['parity']['by_precision']['bf16']['frac_oracle_boxes_iou90']
     p = d['parity']
     assert p['images'] == 4 and 0.5 < p['ap50_vs_oracle'] <= 1.0 and abs(p['G256_bf16']['top1_acc_delta_pt']) <= 2.0
 
