@@ -253,12 +253,12 @@ class _ResBottleneck(nn.Module):
 class _ResNetSource(nn.Module):
     """The attributes of torchvision's ResNet that MACResNet reads (conv1, bn1, relu, maxpool, layer1..4)."""
 
-    def __init__(self, layers=(3, 4, 6, 3), norm_layer=nn.BatchNorm2d):
+    def __init__(self, layers=(3, 4, 6, 3), norm_layer=nn.BatchNorm2d, stem=64, planes=(64, 128, 256, 512)):
         super().__init__()
-        self.conv1, self.bn1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False), norm_layer(64)
+        self.conv1, self.bn1 = nn.Conv2d(3, stem, 7, 2, 3, bias=False), norm_layer(stem)
         self.relu, self.maxpool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
-        inpl = 64
-        for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), layers)):
+        inpl = stem
+        for li, (planes, blocks) in enumerate(zip(planes, layers)):
             seq = []
             for bi in range(blocks):
                 seq.append(_ResBottleneck(inpl, planes, 2 if (bi == 0 and li > 0) else 1, bi == 0, norm_layer))
@@ -289,7 +289,10 @@ class MACResNetEngine:
                         stages.append(('bottleneck', (fold(b.conv1, b.bn1), fold(b.conv2, b.bn2), fold(b.conv3, b.bn3),
                                                       fold(b.downsample[0], b.downsample[1]) if b.downsample is not None else None)))
             self.blocks.append(stages)
-        self.device, self.embedding_size = device, model.embedding_size
+        # width of the descriptor actually produced = channels of the last stage of every block (the reference concatenates
+        # whatever the blocks emit, classification.py:77-84; its `embedding_size` attribute assumes ResNet-50 widths)
+        self.device = device
+        self.embedding_size = sum((st[-1][1].cout if st[-1][0] == 'stem' else st[-1][1][2].cout) for st in self.blocks)
 
     def embed_packed(self, x, eps=1e-8, batch=None):
         """x: (B,S,S,8) bf16 -> (B, embedding_size) f32 unit-norm."""

@@ -31,8 +31,10 @@ def _bottleneck(x, sd, p, stride, has_ds):
 
 
 @torch.no_grad()
-def macresnet_forward(x, sd, desc_layers=(2, 3), eps=1e-8):
-    """(B,3,H,W) f32 -> (B, sum of descriptor-layer channels) unit-norm MAC descriptors."""
+def macresnet_forward(x, sd, desc_layers=(2, 3), eps=1e-8, layers=LAYERS):
+    """(B,3,H,W) f32 -> (B, sum of descriptor-layer channels) unit-norm MAC descriptors.  `layers`: bottlenecks per stage
+    (ResNet-50: 3, 4, 6, 3; the reference-made fixture tests/golden/members.pt uses a smaller hand-built source); channel widths
+    come from the state dict.  Pinned by that fixture: key nesting, per-block amax, concatenation order, L2 normalisation."""
     descs, prev = [], 0
     for bi, l in enumerate(desc_layers):
         for pos, layer in enumerate(range(prev, l + 1)):
@@ -41,7 +43,7 @@ def macresnet_forward(x, sd, desc_layers=(2, 3), eps=1e-8):
                 x = F.relu(_bn(F.conv2d(x, sd[p + '.0.weight'], stride=2, padding=3), sd, p + '.1'))
                 x = F.max_pool2d(x, 3, 2, 1)
             else:
-                for b in range(LAYERS[layer - 1]):
+                for b in range(layers[layer - 1]):
                     x = _bottleneck(x, sd, f'{p}.{b}', 2 if (b == 0 and layer > 1) else 1, b == 0)
         descs.append(x.amax(dim=(-2, -1)))
         prev = l + 1

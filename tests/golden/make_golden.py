@@ -20,6 +20,11 @@ Captured:
                      incl. the reference KAT (test/models/classification_test.py:8-25)
   metrics.pt         metrics KAT inputs + outputs of the reference implementation
                      (cvpce/metrics.py:11-138, test/metrics_test.py:5-21,116-128)
+  members.pt         (round 3; `python tests/golden/make_golden.py members` writes only this file)
+                     MACResNet.forward over a hand-built resnet-like source (cvpce/models/classification.py:53-85): state-dict
+                     key nesting, MAC / concat / L2 norm; Classifier.classify with a toy encoder (cvpce/production.py:57-74):
+                     batching, k, return_embedding, empty input, label lookup; PlanogramComparator.compare early-outs
+                     (production.py:79-90); mean_average_metrics (cvpce/detection_eval.py:51-55)
 """
 import os
 import sys
@@ -73,11 +78,158 @@ def _stub_modules():
     mod('cvpce.models.pix2pix.models', networks=mod('cvpce.models.pix2pix.models.networks'))
 
 
+class TinyBottleneck(nn.Module):
+    """A torchvision-Bottleneck-shaped block (v1.5: stride on the 3x3; attribute names conv1..3 / bn1..3 / downsample) for the
+    hand-built `source_resnet` of the MACResNet fixture.  Written here -- torchvision is absent -- and executed by the REFERENCE's
+    MACResNet.forward through nn.Sequential; what the fixture pins is the reference's own code: the Sequential nesting of the
+    blocks (state-dict keys), the per-block amax, the concatenation order and the L2 normalisation."""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1, self.bn1 = nn.Conv2d(inplanes, planes, 1, bias=False), nn.BatchNorm2d(planes)
+        self.conv2, self.bn2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False), nn.BatchNorm2d(planes)
+        self.conv3, self.bn3 = nn.Conv2d(planes, planes * 4, 1, bias=False), nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4)) if downsample else None
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        return self.relu(self.bn3(self.conv3(y)) + idt)
+
+
+class TinyResNet(nn.Module):
+    def __init__(self, stem=16, planes=(8, 16, 32, 64), layers=(2, 2, 2, 1)):
+        super().__init__()
+        self.conv1, self.bn1 = nn.Conv2d(3, stem, 7, 2, 3, bias=False), nn.BatchNorm2d(stem)
+        self.relu, self.maxpool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+        inpl = stem
+        for li, (pl, nb) in enumerate(zip(planes, layers)):
+            seq = []
+            for bi in range(nb):
+                seq.append(TinyBottleneck(inpl, pl, 2 if (bi == 0 and li > 0) else 1, bi == 0))
+                inpl = pl * 4
+            setattr(self, f'layer{li + 1}', nn.Sequential(*seq))
+
+
+class ToyEncoder(nn.Module):
+    """Encoder stand-in for the Classifier fixture: 4x4 average pool -> linear -> unit norm.  Any nn.Module with an
+    `embedding_size` serves the reference's Classifier (production.py:57-74); what is pinned is Classifier.classify."""
+    embedding_size = 64
+
+    def __init__(self):
+        super().__init__()
+        self.proj = nn.Linear(48, 64, bias=False)
+
+    def forward(self, x):
+        v = self.proj(torch.nn.functional.adaptive_avg_pool2d(x, 4).flatten(1))
+        return v / v.norm(dim=1, keepdim=True).clamp(min=1e-8)
+
+
+def make_members():
+    """members.pt -- see the module docstring."""
+    from cvpce.models import classification as ref_cls
+    from cvpce import metrics as ref_metrics
+    out = {}
+    # ---- (a) MACResNet.forward ------------------------------------------------------------------
+    torch.manual_seed(31)
+    src = TinyResNet()
+    for m in src.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.6, 1.6); m.weight.data.uniform_(0.7, 1.3); m.bias.data.normal_(0, 0.1)
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+    cases = []
+    for dl in ([2, 3], [1, 2, 4], [3]):
+        model = ref_cls.MACResNet(src, dl).eval()
+        x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(len(dl))) * 2 - 1
+        with torch.no_grad():
+            y = model(x)
+            zero = model(torch.zeros(1, 3, 64, 64))          # eps path is not reached (biases), but pins a second input
+        # the model's state dict holds the SAME tensors as the source under the reference's Sequential nesting: store the key map
+        by_ptr = {v.data_ptr(): k for k, v in src.state_dict().items()}
+        cases.append({'descriptor_layers': dl, 'state_key_to_source_key': {k: by_ptr[v.data_ptr()] for k, v in model.state_dict().items()},
+                      'input': x, 'output': y, 'output_zero_input': zero, 'embedding_size_attr': model.embedding_size})
+    out['macresnet'] = {'stem': 16, 'planes': (8, 16, 32, 64), 'layers': (2, 2, 2, 1), 'cases': cases,
+                        'source_state': {k: v.clone() for k, v in src.state_dict().items()}}
+    # ---- (b) Classifier.classify ------------------------------------------------------------------
+    from cvpce import production as ref_prod
+    torch.manual_seed(32)
+    enc = ToyEncoder().eval()
+    g = torch.Generator().manual_seed(33)
+    gal_pat = torch.rand(40, 3, 4, 4, generator=g)            # gallery "products" as 4x4 colour patterns in [0,1]
+    up = lambda p: torch.nn.functional.interpolate(p, size=(256, 256), mode='nearest')
+    with torch.no_grad():
+        gallery = enc(up(gal_pat) * 2 - 1)                     # gallery tensors live in [-1,1] (datautils.py:446)
+    annotations = [f'Food/Cat{i % 7}/{100 + i}.jpg' for i in range(40)]
+    pick = torch.randint(0, 40, (23,), generator=g)
+    q_pat = (gal_pat[pick] + 0.02 * torch.randn(23, 3, 4, 4, generator=g)).clamp(0, 1)
+    cls_cases = []
+    for bs, k, n in ((8, 1, 23), (5, 3, 23), (32, 1, 7), (4, 2, 0), (1, 5, 3)):
+        c = ref_prod.Classifier.__new__(ref_prod.Classifier)
+        c.batch_size, c.num_workers, c.device, c.emb_device, c.k = bs, 0, torch.device('cpu'), torch.device('cpu'), k
+        c.encoder, c.embedding, c.annotations = enc, gallery, annotations
+        imgs = up(q_pat[:n]) if n else torch.empty(0, 3, 256, 256)
+        with torch.no_grad():
+            res = c.classify(imgs)
+            res2, emb = c.classify(imgs, return_embedding=True)
+        assert res == res2
+        cls_cases.append({'batch_size': bs, 'k': k, 'n': n, 'labels': res, 'embedding': emb})
+    out['classifier'] = {'encoder_state': {k_: v.clone() for k_, v in enc.state_dict().items()}, 'gallery_patterns': gal_pat,
+                         'gallery_embedding': gallery, 'annotations': annotations, 'query_patterns': q_pat, 'picked': pick,
+                         'recipe': 'image = F.interpolate(pattern, size=(256, 256), mode="nearest"); gallery images are image * 2 - 1',
+                         'cases': cls_cases}
+    # ---- (c) PlanogramComparator.compare early-outs (production.py:79-90) --------------------------------------------------
+    cmp_ = ref_prod.PlanogramComparator()
+    eb = torch.tensor([[0., 0., 10., 20.], [12., 0., 22., 20.], [24., 0., 34., 20.]])
+    el = ['a', 'b', 'c']
+    none = {'boxes': torch.empty(0, 4), 'labels': []}
+    early = [
+        {'name': 'nothing_detected', 'expected': {'boxes': eb, 'labels': el}, 'actual': none},
+        {'name': 'nothing_expected_nothing_detected', 'expected': none, 'actual': none},
+        {'name': 'no_common_label', 'expected': {'boxes': eb, 'labels': el}, 'actual': {'boxes': eb + 3.0, 'labels': ['x', 'y', 'z']}},
+        {'name': 'nothing_detected_with_image', 'expected': {'boxes': eb, 'labels': el}, 'actual': none, 'image_hw': (40, 50)},
+    ]
+    for e in early:
+        img = torch.zeros(3, *e['image_hw']) if 'image_hw' in e else None
+        e['result'] = float(cmp_.compare(e['expected'], e['actual'], img))
+    out['comparator_early_outs'] = early
+    # ---- (d) mean_average_metrics (detection_eval.py:51-55) ---------------------------------------------------------------
+    from cvpce import detection_eval as ref_de
+    g = torch.Generator().manual_seed(34)
+    per_class, inputs = {}, {}
+    for c in range(4):
+        tg, pr, cf = [], [], []
+        for _ in range(3):
+            nt = int(torch.randint(1, 8, (1,), generator=g))
+            xy = torch.rand(nt, 2, generator=g) * 50
+            t = torch.cat([xy, xy + torch.rand(nt, 2, generator=g) * 20 + 5], 1)
+            npred = int(torch.randint(1, 12, (1,), generator=g))
+            p_ = t[torch.randint(0, nt, (npred,), generator=g)] + torch.randn(npred, 4, generator=g) * 2
+            p_[:, 2:] = torch.max(p_[:, 2:], p_[:, :2] + 1)
+            tg.append(t); pr.append(p_); cf.append(torch.rand(npred, generator=g))
+        inputs[c] = {'targets': tg, 'predictions': pr, 'confidences': cf}
+        r = ref_metrics.calculate_metrics(tg, pr, cf, (0.5, 0.75))
+        per_class[c] = {t: {k_: v for k_, v in d.items() if k_ != 'raw'} for t, d in r.items()}
+    mam = ref_de.mean_average_metrics(per_class, (0.5, 0.75))
+    out['mean_average_metrics'] = {'inputs': inputs, 'per_class': per_class,
+                                   'result': {t: {k_: float(v) for k_, v in d.items()} for t, d in mam.items()}}
+    torch.save(out, os.path.join(HERE, 'members.pt'))
+    print('members.pt written:', os.path.getsize(os.path.join(HERE, 'members.pt')), 'bytes')
+
+
 def main():
     _stub_modules()
     sys.path.insert(0, REF)
     import matplotlib
     matplotlib.use('Agg')
+    if sys.argv[1:] == ['members']:
+        import warnings
+        warnings.simplefilter('ignore')
+        sys.modules['cv2'].findHomography = None
+        sys.modules['cv2'].RANSAC = 8
+        return make_members()
     from cvpce.models import proposals as ref_prop
     from cvpce.models import classification as ref_cls
     from cvpce import metrics as ref_metrics

@@ -8,6 +8,8 @@ after 50+ layers; scores within 0.02; boxes of matched detections within 2 px at
 (1e-3 relative); embeddings cosine > 0.999.  Index outputs are exact whenever the oracle is fed
 the same fp32 head outputs / the same embeddings (stage-isolated), see the tests below.
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -455,3 +457,66 @@ def test_detector_graph_survives_cache_eviction(cuda, gln_model):
     torch.cuda.synchronize()
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)
+
+
+# ---- round 3: reference-made fixtures (tests/golden/members.pt) on the HIP path --------------------------------------------
+def test_macresnet_hip_matches_reference_fixture(cuda, golden_dir):
+    """The HIP MACResNet loaded with the state dict the REFERENCE's MACResNet produced (key nesting pinned by load_state_dict
+    strict=True) against the reference's own output (classification.py:53-85)."""
+    from cvpce_amd.models import classification as C
+    m = torch.load(os.path.join(golden_dir, 'members.pt'), weights_only=False)['macresnet']
+    for case in m['cases']:
+        src = C._ResNetSource(tuple(m['layers']), torch.nn.BatchNorm2d, stem=m['stem'], planes=tuple(m['planes']))
+        model = C.MACResNet(src, list(case['descriptor_layers']))
+        model.load_state_dict({k: m['source_state'][s] for k, s in case['state_key_to_source_key'].items()}, strict=True)
+        assert model.embedding_size == case['embedding_size_attr']
+        out = model.to(cuda)(case['input'].to(cuda)).cpu()
+        assert out.shape == case['output'].shape
+        cos = torch.nn.functional.cosine_similarity(out, case['output'], dim=1)
+        assert cos.min() > 0.9995, cos
+        assert (out - case['output']).abs().max() < 0.02
+
+
+class _ToyEngine:
+    """HIP-side counterpart of the fixture's toy encoder (4x4 average pool -> linear -> unit norm) behind the engine
+    interface Classifier.classify drives: `embed_packed((B,S,S,8) bf16 NHWC, already scale_to_tanh'ed)`."""
+
+    def __init__(self, weight):
+        self.w = weight
+
+    def embed_packed(self, packed):
+        x = packed[..., :3].float().permute(0, 3, 1, 2)
+        v = torch.nn.functional.adaptive_avg_pool2d(x, 4).flatten(1) @ self.w.t()
+        return v / v.norm(dim=1, keepdim=True).clamp(min=1e-8)
+
+
+class _ToyEncoder(torch.nn.Module):
+    embedding_size = 64
+    input_mean, input_std = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+
+    def __init__(self, weight):
+        super().__init__()
+        self._eng = _ToyEngine(weight)
+
+    def engine(self):
+        return self._eng
+
+
+@pytest.mark.parametrize('match_dtype', [torch.float32, torch.bfloat16])
+def test_classifier_classify_matches_reference_fixture(cuda, golden_dir, match_dtype):
+    """Classifier.classify (production.py:57-74) as executed by the REFERENCE with a toy encoder: batching (batch sizes that do
+    not divide the input), k, return_embedding, empty input, label lookup -- same labels from the HIP matcher."""
+    from cvpce_amd import production
+    m = torch.load(os.path.join(golden_dir, 'members.pt'), weights_only=False)['classifier']
+    enc = _ToyEncoder(m['encoder_state']['proj.weight'].to(cuda))
+    up = lambda p: torch.nn.functional.interpolate(p, size=(256, 256), mode='nearest')
+    for case in m['cases']:
+        clf = production.Classifier.from_embedding(enc, m['gallery_embedding'].to(cuda), m['annotations'], device=cuda, emb_device=cuda,
+                                                   batch_size=case['batch_size'], k=case['k'], match_dtype=match_dtype)
+        imgs = up(m['query_patterns'][:case['n']]) if case['n'] else torch.empty(0, 3, 256, 256)
+        labels = clf.classify(imgs.to(cuda))
+        labels2, emb = clf.classify(imgs.to(cuda), return_embedding=True)
+        assert labels == labels2 == case['labels'], (case['batch_size'], case['k'])
+        assert emb.shape == case['embedding'].shape
+        if case['n']:
+            assert (emb.cpu() - case['embedding']).abs().max() < 5e-3      # bf16 rounding of the packed input

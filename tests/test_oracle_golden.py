@@ -52,3 +52,54 @@ def test_distance_matches_reference(golden_dir):
     a, q = case['anchors'], case['queries']
     d = omatch.distance(a[None].expand(len(q), -1, -1), q[:, None].expand(-1, len(a), -1), dim=-1)
     assert d.equal(case['distances'])
+
+
+# ---- round 3: reference-made fixtures for members that run without torchvision (tests/golden/members.pt) -----------------
+def _macresnet_state(m, case):
+    return {k: m['source_state'][src] for k, src in case['state_key_to_source_key'].items()}
+
+
+def test_macresnet_forward_matches_reference(golden_dir):
+    """cvpce/models/classification.py:53-85 executed by the reference over a hand-built resnet-like source: Sequential key
+    nesting, per-block amax, concatenation order, L2 normalisation."""
+    from oracle import macresnet as ores
+    m = _load(golden_dir, 'members.pt')['macresnet']
+    for case in m['cases']:
+        sd = _macresnet_state(m, case)
+        out = ores.macresnet_forward(case['input'], sd, tuple(case['descriptor_layers']), layers=tuple(m['layers']))
+        assert out.shape == case['output'].shape
+        torch.testing.assert_close(out, case['output'], rtol=1e-5, atol=1e-6)
+        zero = ores.macresnet_forward(torch.zeros(1, 3, 64, 64), sd, tuple(case['descriptor_layers']), layers=tuple(m['layers']))
+        torch.testing.assert_close(zero, case['output_zero_input'], rtol=1e-5, atol=1e-6)
+    # the key nesting the reference produces for the default descriptor layers [2, 3]
+    keys = set(m['cases'][0]['state_key_to_source_key'])
+    assert {'blocks.0.0.0.weight', 'blocks.0.0.1.running_var', 'blocks.0.1.0.conv1.weight', 'blocks.0.2.1.bn3.bias',
+            'blocks.1.0.0.downsample.0.weight'} <= keys and not any(k.startswith('blocks.2') for k in keys)
+
+
+def test_mean_average_metrics_matches_reference(golden_dir):
+    """cvpce/detection_eval.py:51-55 on per-class results of the reference's calculate_metrics."""
+    from cvpce_amd import metrics
+    m = _load(golden_dir, 'members.pt')['mean_average_metrics']
+    per_class = {}
+    for c, inp in m['inputs'].items():
+        r = metrics.calculate_metrics(inp['targets'], inp['predictions'], inp['confidences'], (0.5, 0.75))
+        per_class[c] = {t: {k: v for k, v in d.items() if k != 'raw'} for t, d in r.items()}
+        for t in (0.5, 0.75):
+            assert float(per_class[c][t]['ap']) == pytest.approx(float(m['per_class'][c][t]['ap']), abs=1e-6)
+            assert float(per_class[c][t]['ar_300']) == pytest.approx(float(m['per_class'][c][t]['ar_300']), abs=1e-6)
+    # the function under test is host-only arithmetic; cvpce_amd.detection_eval needs the built HIP library to import
+    from cvpce_amd import detection_eval
+    got = detection_eval.mean_average_metrics(per_class, (0.5, 0.75))
+    for t in (0.5, 0.75):
+        assert float(got[t]['map']) == pytest.approx(m['result'][t]['map'], abs=1e-6)
+        assert float(got[t]['mar300']) == pytest.approx(m['result'][t]['mar300'], abs=1e-6)
+
+
+def test_planogram_comparator_early_outs_match_reference(golden_dir):
+    """cvpce/production.py:79-90: nothing detected -> 0 (1 when nothing was expected either), no common subgraph -> 0."""
+    from cvpce_amd import production
+    cmp_ = production.PlanogramComparator()
+    for e in _load(golden_dir, 'members.pt')['comparator_early_outs']:
+        img = torch.zeros(3, *e['image_hw']) if 'image_hw' in e else None
+        assert float(cmp_.compare(e['expected'], e['actual'], img)) == e['result'], e['name']
