@@ -276,11 +276,12 @@ def run_pipeline(args, rank, local_rank, world, dev):
     det, enc = det.to(dev), enc.to(dev)
 
     # gallery: embedded sharded (G/world rows per rank), assembled by ONE all_gather over RCCL/xGMI
-    gal_imgs = synthetic.gallery_images(args.gallery, seed=100)
+    # (every rank materialises only ITS block of the synthetic gallery: 2.5 GB of f32 images at G = 3200 otherwise, per rank)
+    s, e = cdist.shard_range(args.gallery, rank, world)
+    gal_imgs = synthetic.gallery_shard(s, e, seed=100)
     t0 = time.perf_counter()
     embed = lambda x: enc(x.to(dev))
-    s, e = cdist.shard_range(args.gallery, rank, world)
-    local = torch.cat([embed(gal_imgs[i:min(i + 128, e)]) for i in range(s, e, 128)]) if e > s else torch.empty(0, 1024, device=dev)
+    local = torch.cat([embed(gal_imgs[i:i + 128]) for i in range(0, e - s, 128)]) if e > s else torch.empty(0, 1024, device=dev)
     gallery = cdist.all_gather_rows(local, args.gallery, rank, world)
     torch.cuda.synchronize()
     t_gallery = time.perf_counter() - t0
@@ -388,7 +389,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
                    'images_per_gpu': ipg, 'global_images': world * ipg, 'proposals_per_image': proposals, 'gallery': args.gallery,
                    'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
                    'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
-                   'gallery_build_s': round(t_gallery, 3)},
+                   'gallery_build_s': round(t_gallery, 3), 'collectives': cdist.backend_name()},
     }
     if h2d is not None:
         line.update(h2d)
@@ -540,8 +541,8 @@ def main():
     line = {'pipeline': run_pipeline, 'detector': run_detector, 'match-stress': run_match_stress}[args.workload](args, rank, local_rank, world, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

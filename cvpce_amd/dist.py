@@ -16,10 +16,16 @@ def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
+def force_collectives():
+    """CVPCE_DIST_FORCE_COLLECTIVES=1: a 1-rank job still creates its process group and runs every collective of the N-rank
+    path (RCCL smoke test on a one-GPU box: init, all_gather and all_reduce on device tensors, barrier)."""
+    return os.environ.get('CVPCE_DIST_FORCE_COLLECTIVES', '0') == '1'
+
+
 def init(backend=None):
     """One process per GPU (torchrun env).  backend 'nccl' IS RCCL on ROCm; 'gloo' for CPU tests."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -44,7 +50,7 @@ def shard_images(num_images, rank, world):
 
 def all_gather_rows(local, total_rows, rank, world):
     """Assemble a (total_rows, D) matrix from per-rank row blocks laid out by shard_range."""
-    if world == 1:
+    if world == 1 and not (force_collectives() and dist.is_initialized()):
         return local
     sizes = [shard_range(total_rows, r, world) for r in range(world)]
     max_rows = max(e - s for s, e in sizes)
@@ -74,4 +80,12 @@ def max_over_ranks(value, device):
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])     # RCCL: the barrier's all_reduce runs on THIS rank's GPU
+        else:
+            dist.barrier()
+
+
+def backend_name():
+    """'nccl' (= RCCL) | 'gloo' | None when this job runs without a process group."""
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None

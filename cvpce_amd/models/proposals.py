@@ -33,7 +33,10 @@ FPN_CHANNELS = 256
 USE_HEAD_ATLAS = True   # head towers on ONE atlas of the 5 pyramid levels (one launch per tower layer) instead of per level
 N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
 USE_DETECT_GRAPH = True   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
-MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image)
+MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image); LRU
+CAPTURE_ON_SIGHT = 2      # a geometry is captured on its 2nd call (the 1st runs eagerly and fills the host-side caches) ...
+MAX_CAPTURE_ON_SIGHT = 16  # ... and later, up to this many sights, once captured graphs start being evicted barely used (many geometries)
+MAX_SIGHT_COUNTS = 512    # geometries whose call counts are remembered (LRU)
 USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
 USE_ATLAS_COPY = os.environ.get('CVPCE_ATLAS_COPY', '1') != '0'       # levels <-> atlas in one launch each way (15 slice copies otherwise)
 USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
@@ -529,38 +532,56 @@ class GLNEngine:
         return self._detect_tail(batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates)
 
     def _detect_graphed(self, images, num_classes, detections_per_img, conf_thresh):
+        """Graph cache policy (round-2 advisor finding): captured graphs live in an LRU of MAX_DETECT_GRAPHS entries; how often
+        a geometry has been seen is counted in a separate (bounded) table, so first sights never push a captured graph out.
+        A geometry is captured on its `_capture_on_sight`-th call (2 to begin with).  When a graph is evicted after fewer than
+        4 replays -- the mark of a dataset with many image geometries, where capture (synchronise + private pool + eviction
+        churn) costs more than it saves -- the threshold doubles (up to MAX_CAPTURE_ON_SIGHT): only geometries that keep
+        coming back are then captured, everything else runs eagerly."""
         original, resized, padded = self.batch_geometry(images)
         key = (len(images), padded, tuple(resized), tuple(original), num_classes, detections_per_img, float(conf_thresh))
-        graphs = self.__dict__.setdefault('_graphs', {})
+        graphs = self.__dict__.setdefault('_graphs', OrderedDict())
         entry = graphs.get(key)
-        if entry is None:                                  # first sight of this geometry: eager (also fills the host-side caches)
-            while len(graphs) >= MAX_DETECT_GRAPHS:
-                graphs.pop(next(iter(graphs)))
-            graphs[key] = {'graph': None}
+        if entry is not None:                               # captured: replay
+            graphs.move_to_end(key)
+            entry['replays'] += 1
+            self.transform(images, out=entry['static_in'])
+            entry['graph'].replay()
+            # results leave the graph's private memory: a later replay must not overwrite what the caller still holds
+            return ops.clone_views(entry['static_out'])
+        sights = self.__dict__.setdefault('_sights', OrderedDict())
+        seen = sights.pop(key, 0) + 1
+        sights[key] = seen
+        while len(sights) > MAX_SIGHT_COUNTS:
+            sights.popitem(last=False)
+        need = self.__dict__.setdefault('_capture_on_sight', CAPTURE_ON_SIGHT)
+        if seen < need:                                     # not yet: eager (the first call also fills the host-side caches)
             batch, original, resized = self.transform(images)
             return self._detect_tail(batch, original, resized, num_classes, detections_per_img, conf_thresh, False)
-        if entry['graph'] is None:                         # second call: capture
-            static_in = torch.empty((len(images), padded[0], padded[1], 8), dtype=self.dtype, device=self.device)
-            self.transform(images, out=static_in)
-            torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
-            self._capture_refs = []            # engine-owned tensors the captured kernels point at (see _keep)
-            try:
-                # (thread-local capture mode: other threads -- e.g. an RCCL watchdog polling its events -- may keep issuing HIP calls)
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    static_out = self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
-            except Exception:
-                # e.g. a host-side cache was evicted since the first call and would have to be refilled (an upload) inside the
-                # capture: run this call eagerly -- which refills the caches -- and try the capture again next time
-                self.__dict__.pop('_capture_refs', None)
-                torch.cuda.synchronize()
-                return self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
-            entry.update(graph=g, static_in=static_in, static_out=static_out, keepalive=self.__dict__.pop('_capture_refs'))
-        else:
-            self.transform(images, out=entry['static_in'])
-        entry['graph'].replay()
-        # results leave the graph's private memory: a later replay must not overwrite what the caller still holds
-        return ops.clone_views(entry['static_out'])
+        static_in = torch.empty((len(images), padded[0], padded[1], 8), dtype=self.dtype, device=self.device)
+        self.transform(images, out=static_in)
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        self._capture_refs = []            # engine-owned tensors the captured kernels point at (see _keep)
+        try:
+            # (thread-local capture mode: other threads -- e.g. an RCCL watchdog polling its events -- may keep issuing HIP calls)
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                static_out = self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
+        except Exception:
+            # e.g. a host-side cache was evicted since the first call and would have to be refilled (an upload) inside the
+            # capture: run this call eagerly -- which refills the caches -- and try the capture again next time
+            self.__dict__.pop('_capture_refs', None)
+            torch.cuda.synchronize()
+            return self._detect_tail(static_in, original, resized, num_classes, detections_per_img, conf_thresh, False)
+        while len(graphs) >= MAX_DETECT_GRAPHS:            # least recently used captured graph goes
+            _, old = graphs.popitem(last=False)
+            if old['replays'] < 4:
+                self._capture_on_sight = min(MAX_CAPTURE_ON_SIGHT, 2 * self._capture_on_sight)
+        graphs[key] = {'graph': g, 'static_in': static_in, 'static_out': static_out, 'keepalive': self.__dict__.pop('_capture_refs'),
+                       'replays': 0}
+        sights.pop(key, None)
+        g.replay()
+        return ops.clone_views(static_out)
 
     def _detect_tail(self, batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates):
         c2, c3, c4, c5 = self.body(batch)

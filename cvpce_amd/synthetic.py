@@ -81,6 +81,16 @@ def gallery_images(n, seed=100, device='cpu'):
     return (torch.rand(n, 3, 256, 256, generator=g) * 2 - 1).to(device)
 
 
+def gallery_shard(start, end, seed=100, device='cpu'):
+    """Gallery images [start, end) of an unbounded seeded gallery, each from its own generator: a rank materialises only the
+    block it embeds (bench.py shards the gallery build), and image i is the same tensor whatever the world size."""
+    out = torch.empty(max(0, end - start), 3, 256, 256)
+    for j, i in enumerate(range(start, end)):
+        g = torch.Generator().manual_seed(seed * 1000003 + i)
+        out[j] = torch.rand(3, 256, 256, generator=g) * 2 - 1
+    return out.to(device)
+
+
 class TensorGallery:
     """Minimal sample_set for Classifier.build_index: items are (image, annotation)."""
 

@@ -41,6 +41,14 @@ def test_torch_ops_registered_for_the_gpu_only():
     CUDA (= HIP) key only: a CPU tensor is refused by the dispatcher itself -- no CPU kernel exists to fall back to."""
     from cvpce_amd import torch_ops
     declared = {s for s in header_symbols() if not s.endswith('_bytes') and s != 'cvpce_set_persistent_workgroups'}
+    # the fp16 twins of the detector's kernels (round 3) are reached through the SAME ops: the op picks the entry point by the
+    # activations' dtype (torch_ops._by_dtype) -- every twin must have its bf16 original declared too
+    twins = {s for s in declared if s.endswith('_f16')}
+    assert len(twins) == 9
+    for t in twins:
+        base = t[:-4]
+        assert base in declared or base + '_bf16' in declared, t
+    declared -= twins
     # (the two 3x3 halo entry points share one op: Cout <= 128 is forwarded to the wide-tile kernel inside the library)
     assert len(torch_ops.NAMES) == len(declared) == 20   # (two halo entry points share an op; atlas_copy has two)
     for name in torch_ops.NAMES:
@@ -50,6 +58,8 @@ def test_torch_ops_registered_for_the_gpu_only():
     x = torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16)
     with pytest.raises(NotImplementedError, match='CPU'):
         torch.ops.cvpce_amd.relu(x, x.clone())
+    with pytest.raises(NotImplementedError, match='CPU'):
+        torch.ops.cvpce_amd.relu(x.to(torch.float16), x.to(torch.float16))
     with pytest.raises(NotImplementedError, match='CPU'):
         torch.ops.cvpce_amd.match_topk(torch.zeros(2, 64), torch.zeros(3, 64), torch.ones(2), torch.ones(3), 1,
                                        torch.zeros(64, dtype=torch.uint8), torch.zeros(2, 1, dtype=torch.int64), None)

@@ -24,8 +24,9 @@ def _free_port():
     return port
 
 
-def _bench(world, images_per_gpu, self_launch=False):
+def _bench(world, images_per_gpu, self_launch=False, extra_env=None):
     env = dict(os.environ, CVPCE_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra_env or {})
     tail = [os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--images-per-gpu', str(images_per_gpu)] + COMMON
     if world == 1 or self_launch:        # self_launch: `python bench.py --gpus N` starts torch.distributed.run as a child process
         cmd = [sys.executable] + tail
@@ -56,3 +57,15 @@ def test_bench_gpus_flag_starts_the_launcher_itself(cuda):
     finding): it starts the launcher as a child process and relays rank 0's line."""
     two = _bench(2, 1, self_launch=True)
     assert two['n_gpus'] == 2 and two['config']['global_images'] == 2 and two['verify']['images'] == 2
+
+
+def test_rccl_collectives_execute_on_one_gpu(cuda):
+    """RCCL itself, once (round-2 review: every multi-rank rehearsal used gloo): a 1-rank bench run with the `nccl` backend forced
+    creates the process group and runs the N-rank path's collectives for real on device tensors -- the gallery all_gather, the
+    barriers (device_ids) and the max-over-ranks all_reduce -- and must give the same per-image results as the plain 1-rank run."""
+    plain = _bench(1, 2)
+    rccl = _bench(1, 2, extra_env={'CVPCE_DIST_BACKEND': 'nccl', 'CVPCE_DIST_FORCE_COLLECTIVES': '1', 'RANK': '0', 'LOCAL_RANK': '0',
+                                    'WORLD_SIZE': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port())})
+    assert rccl['n_gpus'] == 1 and rccl['value'] > 0
+    assert rccl['verify']['per_image'] == plain['verify']['per_image'] and rccl['verify']['digest'] == plain['verify']['digest']
+    assert rccl['config'].get('collectives') == 'nccl'

@@ -459,6 +459,38 @@ def test_detector_graph_survives_cache_eviction(cuda, gln_model):
         assert torch.equal(x, y) and torch.equal(x, z)
 
 
+def test_detector_graph_cache_policy(cuda):
+    """Round-2 advisor finding: first sights must not evict captured graphs, eviction is LRU, and a stream of many geometries
+    backs the capture threshold off.  Results never depend on whether a call was eager, captured or replayed."""
+    from cvpce_amd import synthetic
+    from cvpce_amd.models import proposals as P
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=50).to(cuda)
+    eng = det.engine()
+    sizes = [(256 + 32 * i, 320) for i in range(7)]
+    imgs = {s: [synthetic.shelf_image(7, *s).to(cuda)] for s in sizes}
+    ref = {s: eng.detect(imgs[s], 1, 50, want_intermediates=True)[0] for s in sizes}      # eager, never captured
+    hot = sizes[0]
+    for _ in range(3):
+        out = eng.detect(imgs[hot], 1, 50)                       # eager, capture, replay
+    assert len(eng._graphs) == 1 and eng._capture_on_sight == P.CAPTURE_ON_SIGHT
+    for s in sizes[1:]:                                          # six first sights: nothing is captured, nothing evicted
+        out = eng.detect(imgs[s], 1, 50)
+        for x, y in zip(out, ref[s]):
+            assert torch.equal(x, y)
+    assert len(eng._graphs) == 1 and next(iter(eng._graphs.values()))['replays'] == 1
+    for s in sizes[1:]:                                          # second sights: captured one by one, LRU keeps at most 4
+        eng.detect(imgs[hot], 1, 50)                             # the hot geometry keeps being replayed -> most recently used
+        out = eng.detect(imgs[s], 1, 50)
+        for x, y in zip(out, ref[s]):
+            assert torch.equal(x, y)
+        assert len(eng._graphs) <= P.MAX_DETECT_GRAPHS
+    assert any(k[2] == (P.resized_hw(*hot),) for k in eng._graphs), 'the hot geometry was evicted'
+    assert eng._capture_on_sight > P.CAPTURE_ON_SIGHT            # barely-used graphs were evicted: capture now needs more sights
+    out = eng.detect(imgs[hot], 1, 50)
+    for x, y in zip(out, ref[hot]):
+        assert torch.equal(x, y)
+
+
 # ---- round 3: reference-made fixtures (tests/golden/members.pt) on the HIP path --------------------------------------------
 def test_macresnet_hip_matches_reference_fixture(cuda, golden_dir):
     """The HIP MACResNet loaded with the state dict the REFERENCE's MACResNet produced (key nesting pinned by load_state_dict
