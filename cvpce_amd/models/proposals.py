@@ -278,9 +278,10 @@ class GLNEngine:
         self.num_anchors = self.base_anchors.shape[1]
         self.device = device
 
-    def pack_gaussian(self, gl, subnet, device):
+    def pack_gaussian(self, gl, subnet, device, dtype=None):
         """Gaussian branch weights (proposals.py:65-107): eval-mode BatchNorm folded into block1/block2."""
-        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, dtype=self.dtype, **kw)
+        dt = dtype if dtype is not None else getattr(self, 'dtype', ops.BF16)
+        P = lambda conv, **kw: ops.PackedConv(conv.weight, conv.bias, conv.stride[0], conv.padding[0], device=device, dtype=dt, **kw)
 
         def fold_bn(blk):
             bn = blk.norm

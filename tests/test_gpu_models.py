@@ -311,17 +311,16 @@ def test_gaussian_branch_vs_reference_golden(cuda, golden_dir, tanh):
     subnet.load_state_dict(g['subnet_state'])
     for i, blk in enumerate(subnet.blocks):
         blk.conv = widen_conv(blk.conv, 8, 1 if i == 4 else 8)
-    eng = P.GLNEngine.__new__(P.GLNEngine)
-    eng.pack_gaussian(layer.eval(), subnet, cuda)
-
-    def nhwc(x):
-        return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(cuda)
-
-    out = eng.gaussian_branch(nhwc(g['c2']), nhwc(g['p3'])).permute(0, 3, 1, 2).cpu()
-    assert out.shape == g['gaussians'].shape
-    # bf16 storage of inputs/weights/7 intermediate tensors vs the reference's fp32
-    assert l2rel(out, g['gaussians']) < 3e-2, l2rel(out, g['gaussians'])
-    assert (out - g['gaussians']).abs().max() < 0.05 * g['gaussians'].abs().max() + 1e-2
+    # both storage modes against the REFERENCE's fp32 output: bf16 (default) and the fp16 accuracy mode
+    for dt, l2tol, abstol in ((torch.bfloat16, 3e-2, 0.05), (torch.float16, 4e-3, 0.006)):
+        eng = P.GLNEngine.__new__(P.GLNEngine)
+        eng.pack_gaussian(layer.eval(), subnet, cuda, dtype=dt)
+        nhwc = lambda x: x.permute(0, 2, 3, 1).contiguous().to(dt).to(cuda)
+        out = eng.gaussian_branch(nhwc(g['c2']), nhwc(g['p3'])).permute(0, 3, 1, 2).cpu()
+        assert out.shape == g['gaussians'].shape
+        # 16-bit storage of inputs / weights / 7 intermediate tensors vs the reference's fp32
+        assert l2rel(out, g['gaussians']) < l2tol, (dt, l2rel(out, g['gaussians']))
+        assert (out - g['gaussians']).abs().max() < abstol * g['gaussians'].abs().max() + (1e-2 if dt == torch.bfloat16 else 1e-3), dt
 
 
 @pytest.mark.parametrize('hw', [(100, 100), (64, 88), (20, 37)])
