@@ -203,23 +203,26 @@ def gather_digests(local, world):
     return merged
 
 
-def timed_windows(step, steps, windows, dev):
+def timed_windows(step, steps, windows, dev, collective=True):
     """`windows` back-to-back timed regions of EXACTLY `steps` calls of `step()`, each bracketed by barrier +
     torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  -> (median seconds, [seconds per window]).
     One window of ~1 s decides little on a power-limited part with +-3 % box-to-box spread; the line reports the median
-    and the spread."""
+    and the spread.  collective=False: a rank-0-only side leg (no barrier, no reduction: the other ranks are not there)."""
     from cvpce_amd import dist as cdist
     secs = []
     for _ in range(max(1, windows)):
         torch.cuda.synchronize()
-        cdist.barrier()
-        torch.cuda.synchronize()
+        if collective:
+            cdist.barrier()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        cdist.barrier()
-        secs.append(cdist.max_over_ranks(time.perf_counter() - t0, dev))
+        if collective:
+            cdist.barrier()
+        dt = time.perf_counter() - t0
+        secs.append(cdist.max_over_ranks(dt, dev) if collective else dt)
     return sorted(secs)[len(secs) // 2], secs
 
 
@@ -370,7 +373,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     if not args.no_workloads and rank == 0:
         # BASELINE configs[1] and configs[3] on this same box (a few hundred ms of GPU time): the driver only runs the default line
         del pipe, out, outs
-        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision)
+        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False)
         workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
                      'match_stress_configs3': match_stress_cases(dev, 200, 3)}
 
@@ -403,7 +406,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
 # ---------------------------------------------------------------------------------------------------------------------
 # workload: detector only (BASELINE configs[1])
 # ---------------------------------------------------------------------------------------------------------------------
-def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16', ids=None, windows=1, want_profile=False):
+def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16', ids=None, windows=1, want_profile=False, collective=True):
     """`ipg` shelf images through the GLN detector only (transform, ResNet-50 + FPN, Gaussian branch, heads, top-k / NMS), the
     graph-replayed schedule `GLNEngine.detect` runs in production.  -> dict of figures (+ the engine / model for the caller)."""
     from cvpce_amd import ops, synthetic
@@ -418,7 +421,7 @@ def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16'
 
     for _ in range(warmup):
         step()
-    elapsed, secs = timed_windows(step, steps, windows, dev)
+    elapsed, secs = timed_windows(step, steps, windows, dev, collective)
     ms = elapsed / steps * 1e3
     gf = 298.4 * ipg
     res = {'images': ipg, 'image_size': image_size, 'detections_per_img': dpi, 'precision': precision, 'ms_per_step': round(ms, 3),
