@@ -37,6 +37,7 @@ SIGNATURES = {
     'cvpce_conv3x3_halo': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_conv3x3_halo_mac': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 8 + [_vp]),
     'cvpce_conv3x3_halo_wide': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),
+    'cvpce_bottleneck_fused': (c_int, [_vp, _vp, _vp, _fp, _vp, _fp, _vp, _fp, _vp] + [c_int] * 11 + [_vp]),
     'cvpce_conv3x3_halo_masked': (c_int, [_vp, _vp, _fp, _vp, _vp, c_int, _vp] + [c_int] * 8 + [_vp]),
     'cvpce_maxpool2d_nhwc_bf16': (c_int, [_vp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_relu_bf16': (c_int, [_vp, _vp, c_longlong, _vp]),
@@ -60,6 +61,7 @@ SIGNATURES = {
 for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16'),
                      ('cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16'), ('cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16'),
                      ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
+                     ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'),
                      ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'),
                      ('cvpce_gln_transform', 'cvpce_gln_transform_f16')):
     SIGNATURES[_twin] = SIGNATURES[_base]

@@ -329,6 +329,12 @@ class GLNEngine:
         for blocks in self.layers:
             for c1, c2, c3, ds in blocks:
                 # the projection shortcut of a stage's first block is independent of conv1 -> conv2: beside them
+                if ds is None and ops.can_fuse_bottleneck(x, c1, c2, c3, x):
+                    x = ops.bottleneck(x, c1, c2, c3, x)           # identity block: one launch, intermediates in LDS
+                    continue
+                if ds is not None and ops.can_fuse_bottleneck(x, c1, c2, c3, x.new_empty((x.shape[0], x.shape[1], x.shape[2], c3.cout))):
+                    x = ops.bottleneck(x, c1, c2, c3, ops.conv2d(x, ds))   # layer1's first block (stride 1): shortcut conv, then one launch
+                    continue
                 identity, joined = self._beside(2, lambda: ops.conv2d(x, ds)) if ds is not None else (x, None)
                 y = ops.conv2d(x, c1, act=1)
                 y = ops.conv2d(y, c2, act=1)

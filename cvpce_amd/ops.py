@@ -180,6 +180,40 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     return out
 
 
+USE_FUSED_BOTTLENECK = _os.environ.get('CVPCE_FUSED_BOTTLENECK', '1') != '0'   # A/B switch: stride-1 ResNet bottlenecks (P <= 256) in one launch (csrc/bneck.hip)
+
+
+def can_fuse_bottleneck(x, c1, c2, c3, residual):
+    """cvpce_bottleneck_fused covers: 1x1 (s1) -> 3x3 (s1, p1) -> 1x1 (s1), planes P in {64, 128, 256}, 4P outputs, a same-size residual."""
+    p = c1.cout
+    n, h, w, cin = x.shape
+    return (USE_FUSED_BOTTLENECK and not FORCE_GENERIC_CONV and p in (64, 128, 256) and cin % 64 == 0 and c1.cin_pad == cin
+            and (c1.kh, c1.stride, c1.pad) == (1, 1, 0) and (c2.kh, c2.kw, c2.stride, c2.pad) == (3, 3, 1, 1) and c2.cin == p and c2.cout == p
+            and (c3.kh, c3.stride, c3.pad) == (1, 1, 0) and c3.cin == p and c3.cout == 4 * p and c2.k_pad == 9 * p
+            and all(c.bias is not None for c in (c1, c2, c3)) and residual is not None and tuple(residual.shape) == (n, h, w, 4 * p)
+            and n * h * w * max(cin, 4 * p) * 2 < 2 ** 32)
+
+
+def bottleneck(x, c1, c2, c3, residual):
+    """relu(c3(relu(c2(relu(c1(x))))) + residual) -- one ResNet bottleneck block (stride 1) in ONE launch."""
+    _need_cuda(x, residual)
+    assert can_fuse_bottleneck(x, c1, c2, c3, residual) and x.dtype == c1.dtype == c2.dtype == c3.dtype == residual.dtype
+    assert x.is_contiguous() and residual.is_contiguous()
+    n, h, w, cin = x.shape
+    p = c1.cout
+    out = torch.empty((n, h, w, 4 * p), dtype=x.dtype, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.bottleneck_fused(x, residual, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, out, p, c1.k_pad, c2.k_pad, c3.k_pad,
+                       c1.cout_pad, c2.cout_pad, c3.cout_pad)
+    if prof is not None:
+        e1.record()
+        prof.records.append(('bneck_kernel', 2.0 * n * h * w * (cin * p + 9 * p * p + 4 * p * p), e0, e1))
+    return out
+
+
 USE_FUSED_MAC = True   # A/B switch: MAC descriptor (+ pool4, + no store of conv5_3) fused into the conv epilogue
 
 

@@ -96,6 +96,15 @@ def _conv3x3_halo_masked(x, weight, bias, mask, tile_map, out, cout, k_pad, cout
              _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, _stream()), 'cvpce_conv3x3_halo_masked')
 
 
+@_op('bottleneck_fused(Tensor x, Tensor res, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor w3, Tensor b3, Tensor(a!) out, int planes, '
+     'int k1_pad, int k2_pad, int k3_pad, int c1_pad, int c2_pad, int c3_pad) -> ()')
+def _bottleneck_fused(x, res, w1, b1, w2, b2, w3, b3, out, planes, k1_pad, k2_pad, k3_pad, c1_pad, c2_pad, c3_pad):
+    n, h, w, cin = x.shape
+    fn = _by_dtype(x, 'cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16', res, w1, w2, w3, out)
+    check(fn(_p(x), _p(res), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(out), n, h, w, cin, planes, k1_pad, k2_pad, k3_pad,
+             c1_pad, c2_pad, c3_pad, _stream()), 'cvpce_bottleneck_fused')
+
+
 @_op('vgg_stem_fused(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out) -> ()')
 def _vgg_stem_fused(x, w1, b1, w2, b2, out):
     n, h, w, c = x.shape

@@ -101,6 +101,17 @@ int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias
                               const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
                               int Cout_pad, int relu, void* stream);
 
+/* One ResNet-50 bottleneck block (torchvision `Bottleneck`, v1.5, STRIDE 1, FrozenBatchNorm2d folded into weights and biases;
+ * reached from cvpce/models/proposals.py:202-216) in one launch, the two P-channel intermediates held in LDS:
+ *   out = relu( conv1x1_w3( relu( conv3x3_w2( relu( conv1x1_w1(x) + b1 ) ) + b2 ) ) + b3 + res )
+ * x: [N][H][W][Cin] (Cin % 64 == 0), res / out: [N][H][W][4P] (res = x for the identity blocks, else the projection
+ * shortcut's output), P in {64, 128, 256} (layer1 / layer2 / layer3).  Weights in the layouts of cvpce_conv2d_nhwc_bf16:
+ * w1 [c1_pad][k1_pad] (k = ci), w2 [c2_pad][k2_pad = 9P] chunk-major, w3 [c3_pad][k3_pad] (k = ci); biases fp32, required.
+ * Same rounding points as the three separate launches (both intermediates are rounded to the storage type). */
+int cvpce_bottleneck_fused(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
+                           const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, int k1_pad, int k2_pad,
+                           int k3_pad, int c1_pad, int c2_pad, int c3_pad, void* stream);
+
 /* Upper bound on the workgroups the persistent convolution kernels launch (default 256 = one per CU).  A host that
  * runs them on a stream restricted to fewer CUs (hipExtStreamCreateWithCUMask) sets the bound to that CU count.
  * Process-wide; 1 <= n <= 256. */
@@ -187,6 +198,9 @@ int cvpce_conv3x3_halo_wide_f16(const void* in, const void* wgt, const float* bi
 int cvpce_conv3x3_halo_masked_f16(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
                                   const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
                                   int Cout_pad, int relu, void* stream);
+int cvpce_bottleneck_fused_f16(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
+                               const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, int k1_pad, int k2_pad,
+                               int k3_pad, int c1_pad, int c2_pad, int c3_pad, void* stream);
 int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
                              int Ho, int Wo, void* stream);
 int cvpce_relu_f16(const void* in, void* out, long long n, void* stream);

@@ -674,3 +674,61 @@ def test_crop_resize_narrow_pixels(cuda):
     std = torch.tensor(C.TANH_STD)[None, :, None, None]
     want = ((v * 2.0 - 1.0 - mean) / std).to(torch.bfloat16).permute(0, 2, 3, 1)
     assert torch.equal(b[..., :3].cpu(), want)
+
+
+BNECK_CASES = [  # n, cin, planes, h, w, separate residual tensor (the projection-shortcut case)
+    (2, 256, 64, 56, 56, False),      # layer1 identity block, tiles exact (4 x 14)
+    (1, 64, 64, 37, 51, True),        # layer1 first block: Cin = 64, residual = shortcut conv; ragged tiles
+    (2, 512, 128, 100, 100, False),   # layer2
+    (1, 512, 128, 5, 9, False),       # smaller than one tile
+    (2, 1024, 256, 50, 50, False),    # layer3
+    (1, 1024, 256, 15, 29, False),    # layer3, one pixel past a tile edge
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,cin,p,h,w,sep', BNECK_CASES)
+def test_bottleneck_fused_parity(cuda, dtype, n, cin, p, h, w, sep):
+    """cvpce_bottleneck_fused (1x1 -> 3x3 -> 1x1 + residual, intermediates in LDS) against the three-launch HIP schedule (same
+    rounding points: within two ulps of the storage type, almost everywhere identical) and against the oracle ops on the same
+    16-bit-rounded operands."""
+    from cvpce_amd import ops
+    rd = lambda t: t.to(dtype).to(torch.float32)
+    g = torch.Generator().manual_seed(zlib.crc32(f'bneck/{n}/{cin}/{p}/{h}/{w}'.encode()))
+    x = rd(torch.randn(n, cin, h, w, generator=g))
+    mk = lambda co, ci, k: (torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k), torch.randn(co, generator=g) * 0.1)
+    (w1, b1), (w2, b2), (w3, b3) = mk(p, cin, 1), mk(p, p, 3), mk(4 * p, p, 1)
+    res = rd(torch.randn(n, 4 * p, h, w, generator=g)) if sep else x
+    assert sep or cin == 4 * p
+    pcs = [ops.PackedConv(w_, b_, 1, pad, device=cuda, dtype=dtype) for (w_, b_, pad) in ((w1, b1, 0), (w2, b2, 1), (w3, b3, 0))]
+    to_dev = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype).to(cuda)
+    xd = to_dev(x)
+    rdv = to_dev(res) if sep else xd
+    assert ops.can_fuse_bottleneck(xd, *pcs, rdv)
+    y = ops.bottleneck(xd, *pcs, rdv)
+    ops.USE_FUSED_BOTTLENECK = False
+    try:
+        m1 = ops.conv2d(xd, pcs[0], act=1)
+        m2 = ops.conv2d(m1, pcs[1], act=1)
+        y3 = ops.conv2d(m2, pcs[2], act=1, residual=rdv)
+    finally:
+        ops.USE_FUSED_BOTTLENECK = True
+    torch.cuda.synchronize()
+    assert y.shape == y3.shape == (n, h, w, 4 * p) and y.dtype == dtype
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    d = (y.float() - y3.float()).abs()
+    assert float(d.max()) <= 2.5 * ulp * float(y3.float().abs().max()), float(d.max())
+    assert float((y != y3).float().mean()) < 0.05
+    t1 = rd(F.relu(F.conv2d(x, rd(w1), b1)))
+    t2 = rd(F.relu(F.conv2d(t1, rd(w2), b2, padding=1)))
+    ref = F.relu(F.conv2d(t2, rd(w3), b3) + res)
+    assert rel_err(nchw(y), ref) < (1.5e-2 if dtype == torch.bfloat16 else 3e-3), rel_err(nchw(y), ref)
+
+
+def test_bottleneck_fused_rejects_what_it_does_not_cover(cuda):
+    from cvpce_amd import ops
+    x = torch.zeros(1, 8, 8, 2048, dtype=BF, device=cuda)
+    mk = lambda co, ci, k, s=1: ops.PackedConv(torch.zeros(co, ci, k, k), torch.zeros(co), s, k // 2, device=cuda)
+    assert not ops.can_fuse_bottleneck(x, mk(512, 2048, 1), mk(512, 512, 3), mk(2048, 512, 1), x)          # layer4: P = 512 does not fit the LDS
+    x2 = torch.zeros(1, 8, 8, 256, dtype=BF, device=cuda)
+    assert not ops.can_fuse_bottleneck(x2, mk(128, 256, 1), mk(128, 128, 3, 2), mk(512, 128, 1), torch.zeros(1, 4, 4, 512, dtype=BF, device=cuda))  # stride 2

@@ -22,7 +22,7 @@ for kind in ('fetch', 'write'):
     rows_ = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
     # only the launches of the LAST pipeline pass (= one timed step of bench.py: it starts with the 8 transform launches of the
     # step's images); the gallery build and the warm-up pass launch the same kernels on other batch sizes
-    marks = [int(r['Dispatch_Id']) for r in rows_ if r['Kernel_Name'].startswith('gln_transform_kernel')]
+    marks = [int(r['Dispatch_Id']) for r in rows_ if 'gln_transform_kernel' in r['Kernel_Name']]
     first = marks[-8] if len(marks) >= 8 else 0
     for r in rows_:
         if int(r['Dispatch_Id']) >= first:

@@ -11,8 +11,8 @@ a = ap.parse_args()
 f = glob.glob(a.dir + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(a.marker)]
-ends = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(a.end_marker)]
+marks = [i for i, r in enumerate(rows) if a.marker in r['Kernel_Name']]
+ends = [i for i, r in enumerate(rows) if a.end_marker in r['Kernel_Name']]
 starts = marks[::a.marker_per_step][-a.steps:]
 tot = collections.defaultdict(lambda: [0, 0.0])
 span = busy = 0.0

@@ -7,7 +7,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
 kernel = sys.argv[2] if len(sys.argv) > 2 else 'void conv3x3_halo2_kernel'
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('gln_transform_kernel')]
+marks = [i for i, r in enumerate(rows) if 'gln_transform_kernel' in r['Kernel_Name']]
 bursts = []
 for m in marks:
     if not bursts or m - bursts[-1][-1] > 40:
@@ -19,9 +19,9 @@ for bi, b in enumerate(bursts):
     s = b[0]
     e = bursts[bi + 1][0] if bi + 1 < len(bursts) else len(rows)
     if bi + 1 == len(bursts):       # last burst: stop at the end of its own pipeline pass (what follows are other legs)
-        ends = [i for i in range(s, len(rows)) if rows[i]['Kernel_Name'].startswith('match_merge_kernel') or rows[i]['Kernel_Name'].startswith('void match_kernel')]
+        ends = [i for i in range(s, len(rows)) if 'match_merge_kernel' in rows[i]['Kernel_Name'] or rows[i]['Kernel_Name'].startswith('void match_kernel')]
         e = (ends[0] + 1) if ends else e
-    h = [r for r in rows[s:e] if r['Kernel_Name'].startswith(kernel)]
+    h = [r for r in rows[s:e] if kernel in r['Kernel_Name']]
     d = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in h) / 1e3
     span = (max(int(r['End_Timestamp']) for r in rows[s:e]) - int(rows[s]['Start_Timestamp'])) / 1e6
     print(f'| {bi} | {len(b)} | {span:.1f} | {len(h)} | {d / max(1, len(h)):.1f} | {d / 1e3:.1f} |')
