@@ -44,6 +44,8 @@ SIGNATURES = {
     'cvpce_global_max_nhwc_bf16': (c_int, [_vp, _fp, c_int, c_int, c_int, c_int, c_int, _vp]),
     'cvpce_l2_normalize_f32': (c_int, [_fp, _fp, _vp, c_int, c_int, c_float, _vp]),
     'cvpce_gln_transform': (c_int, [_fp, _vp] + [c_int] * 6 + [POINTER(c_float), POINTER(c_float), _vp]),
+    'cvpce_gln_transform_batch': (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int, _vp, c_int, c_int,
+                                          POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_crop_resize': (c_int, [_fp, _fp, _ip, c_int, _vp, c_int, c_int, c_int, c_int,
                                   POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_pack_embed_input': (c_int, [_fp, _vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _vp]),
@@ -54,6 +56,8 @@ SIGNATURES = {
                                          _vp, c_size_t, _fp, _fp, _vp, _ip, _ip, _vp]),
     'cvpce_row_norms': (c_int, [_vp, _fp, c_int, c_int, c_int, c_float, _vp]),
     'cvpce_match_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cvpce_match_fused_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cvpce_match_topk_fused': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, _vp, c_size_t, _ip, c_int, _vp, _fp, _vp]),
     'cvpce_probe_mfma_bf16': (c_int, [c_int, c_int, _vp, _fp, c_int, _vp]),
     'cvpce_match_topk': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _vp, c_size_t, _vp, _fp, _vp]),
 }
@@ -63,7 +67,7 @@ for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpc
                      ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
                      ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'),
                      ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'),
-                     ('cvpce_gln_transform', 'cvpce_gln_transform_f16')):
+                     ('cvpce_gln_transform', 'cvpce_gln_transform_f16'), ('cvpce_gln_transform_batch', 'cvpce_gln_transform_batch_f16')):
     SIGNATURES[_twin] = SIGNATURES[_base]
 
 for _name, (_res, _args) in SIGNATURES.items():

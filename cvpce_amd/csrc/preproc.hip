@@ -65,6 +65,76 @@ static int gln_transform_dispatch(const float* img, void* out_nhwc8, int H0, int
     return cvpce_check_launch();
 }
 
+// The whole batch in ONE launch (grid.z = image): on the detector's critical chain eight 12-us launches in a row cost 0.1 ms.
+struct TransformBatchArgs {
+    const float* img[32];
+    int H0[32], W0[32], h[32], w[32];
+};
+
+template <typename E>
+__global__ void gln_transform_batch_kernel(TransformBatchArgs a, bf16_t* __restrict__ out, int Hp, int Wp, float m0, float m1, float m2,
+                                           float s0, float s1, float s2) {
+    const int i = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wp) return;
+    const float* __restrict__ img = a.img[i];
+    const int H0 = a.H0[i], W0 = a.W0[i], h = a.h[i], w = a.w[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+    if (y < h && x < w) {                                   // (the arithmetic of gln_transform_kernel, operation for operation)
+        const float sy = (float)H0 / (float)h, sx = (float)W0 / (float)w;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(sy, y, H0, y0, y1, ly0, ly1);
+        src_index(sx, x, W0, x0, x1, lx0, lx1);
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* p = img + (size_t)c * H0 * W0;
+            float v00 = (p[(size_t)y0 * W0 + x0] - mean[c]) / stdv[c];
+            float v01 = (p[(size_t)y0 * W0 + x1] - mean[c]) / stdv[c];
+            float v10 = (p[(size_t)y1 * W0 + x0] - mean[c]) / stdv[c];
+            float v11 = (p[(size_t)y1 * W0 + x1] - mean[c]) / stdv[c];
+            float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            o[c] = E::narrow(v);
+        }
+    }
+    *reinterpret_cast<bf16x8*>(out + (((size_t)i * Hp + y) * Wp + x) * 8) = o;
+}
+
+template <typename E>
+static int gln_transform_batch_dispatch(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,
+                                        void* out_nhwc8, int Hp, int Wp, const float* mean3, const float* std3, void* stream) {
+    if (n <= 0) return CVPCE_OK;
+    if (!imgs || !H0 || !W0 || !h || !w || !out_nhwc8 || !mean3 || !std3 || Hp <= 0 || Wp <= 0) return CVPCE_ERR_ARG;
+    for (int base = 0; base < n; base += 32) {
+        const int m = n - base < 32 ? n - base : 32;
+        TransformBatchArgs a;
+        for (int i = 0; i < 32; ++i) {
+            const int j = base + (i < m ? i : 0);
+            if (!imgs[j] || h[j] > Hp || w[j] > Wp || h[j] <= 0 || w[j] <= 0 || H0[j] <= 0 || W0[j] <= 0) return CVPCE_ERR_ARG;
+            a.img[i] = imgs[j]; a.H0[i] = H0[j]; a.W0[i] = W0[j]; a.h[i] = h[j]; a.w[i] = w[j];
+        }
+        dim3 grid((Wp + 127) / 128, Hp, m);
+        hipLaunchKernelGGL(gln_transform_batch_kernel<E>, grid, dim3(128), 0, (hipStream_t)stream, a,
+                           (bf16_t*)out_nhwc8 + (size_t)base * Hp * Wp * 8, Hp, Wp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+        const int rc = cvpce_check_launch();
+        if (rc != CVPCE_OK) return rc;
+    }
+    return CVPCE_OK;
+}
+
+extern "C" int cvpce_gln_transform_batch(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,
+                                         void* out_nhwc8, int Hp, int Wp, const float* mean3, const float* std3, void* stream) {
+    return gln_transform_batch_dispatch<ElemBF16>(imgs, H0, W0, h, w, n, out_nhwc8, Hp, Wp, mean3, std3, stream);
+}
+extern "C" int cvpce_gln_transform_batch_f16(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,
+                                             void* out_nhwc8, int Hp, int Wp, const float* mean3, const float* std3, void* stream) {
+    return gln_transform_batch_dispatch<ElemF16>(imgs, H0, W0, h, w, n, out_nhwc8, Hp, Wp, mean3, std3, stream);
+}
+
 extern "C" int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
                                    const float* mean3, const float* std3, void* stream) {
     return gln_transform_dispatch<ElemBF16>(img, out_nhwc8, H0, W0, h, w, Hp, Wp, mean3, std3, stream);

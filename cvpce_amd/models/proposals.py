@@ -39,6 +39,7 @@ MAX_CAPTURE_ON_SIGHT = 16  # ... and later, up to this many sights, once capture
 MAX_SIGHT_COUNTS = 512    # geometries whose call counts are remembered (LRU)
 USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
 USE_ATLAS_COPY = os.environ.get('CVPCE_ATLAS_COPY', '1') != '0'       # levels <-> atlas in one launch each way (15 slice copies otherwise)
+USE_BATCHED_TRANSFORM = os.environ.get('CVPCE_BATCHED_TRANSFORM', '1') != '0'   # the input transform of a whole batch in one launch
 USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
 
 
@@ -315,8 +316,11 @@ class GLNEngine:
         sizes, rs, (hp, wp) = self.batch_geometry(images)
         batch = out if out is not None else torch.empty((len(images), hp, wp, 8), dtype=self.dtype, device=self.device)
         assert tuple(batch.shape) == (len(images), hp, wp, 8) and batch.dtype == self.dtype
-        for i, (img, (h, w)) in enumerate(zip(images, rs)):
-            ops.gln_transform_into(img.contiguous(), batch, i, h, w, IMAGE_MEAN, IMAGE_STD)
+        if USE_BATCHED_TRANSFORM:
+            ops.gln_transform_batch(images, batch, rs, IMAGE_MEAN, IMAGE_STD)
+        else:
+            for i, (img, (h, w)) in enumerate(zip(images, rs)):
+                ops.gln_transform_into(img.contiguous(), batch, i, h, w, IMAGE_MEAN, IMAGE_STD)
         return batch, sizes, rs
 
     def body(self, x):

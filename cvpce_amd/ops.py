@@ -183,11 +183,14 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
 USE_FUSED_BOTTLENECK = _os.environ.get('CVPCE_FUSED_BOTTLENECK', '1') != '0'   # A/B switch: stride-1 ResNet bottlenecks (P <= 256) in one launch (csrc/bneck.hip)
 
 
+FUSED_BOTTLENECK_MAX_PLANES = int(_os.environ.get('CVPCE_FUSED_BOTTLENECK_MAXP', '64'))   # measured (tools/dev/bench_bneck.py, profiles/r03_bneck.md): layer1 (P = 64) wins, P = 128 / 256 lose -- their tiles are too few and too long
+
+
 def can_fuse_bottleneck(x, c1, c2, c3, residual):
     """cvpce_bottleneck_fused covers: 1x1 (s1) -> 3x3 (s1, p1) -> 1x1 (s1), planes P in {64, 128, 256}, 4P outputs, a same-size residual."""
     p = c1.cout
     n, h, w, cin = x.shape
-    return (USE_FUSED_BOTTLENECK and not FORCE_GENERIC_CONV and p in (64, 128, 256) and cin % 64 == 0 and c1.cin_pad == cin
+    return (USE_FUSED_BOTTLENECK and not FORCE_GENERIC_CONV and p in (64, 128, 256) and p <= FUSED_BOTTLENECK_MAX_PLANES and cin % 64 == 0 and c1.cin_pad == cin
             and (c1.kh, c1.stride, c1.pad) == (1, 1, 0) and (c2.kh, c2.kw, c2.stride, c2.pad) == (3, 3, 1, 1) and c2.cin == p and c2.cout == p
             and (c3.kh, c3.stride, c3.pad) == (1, 1, 0) and c3.cin == p and c3.cout == 4 * p and c2.k_pad == 9 * p
             and all(c.bias is not None for c in (c1, c2, c3)) and residual is not None and tuple(residual.shape) == (n, h, w, 4 * p)
@@ -407,6 +410,14 @@ def gln_transform_into(img, batch, index, h, w, mean, std):
     T.gln_transform(img, batch, index, h, w, [float(v) for v in mean], [float(v) for v in std])
 
 
+def gln_transform_batch(images, batch, sizes, mean, std):
+    """images[i] (3,H0,W0) f32 cuda -> batch[i] (Hp,Wp,8), resized to sizes[i] = (h, w): the whole batch in one launch."""
+    _need_cuda(batch, *images)
+    assert batch.shape[0] == len(images) == len(sizes) and batch.shape[3] == 8 and batch.is_contiguous()
+    T.gln_transform_batch([i.contiguous() for i in images], batch, [int(s[0]) for s in sizes], [int(s[1]) for s in sizes],
+                          [float(v) for v in mean], [float(v) for v in std])
+
+
 MAX_CROPS_PER_LAUNCH = 65535
 
 
@@ -507,6 +518,23 @@ def row_norms(x, eps=1e-8):
     return out
 
 
+USE_FUSED_MATCH = _os.environ.get('CVPCE_FUSED_MATCH', '1') != '0'   # A/B switch: bf16 matcher as ONE launch (cvpce_match_topk_fused)
+MATCH_COUNTERS = 64                 # query tiles of 256 a call may have (16 384 queries); more -> the two-launch kernels
+_MATCH_COUNTER_CACHE = {}
+
+
+def _match_counters(device):
+    """The zero-initialised ticket array of cvpce_match_topk_fused, one per (device, stream): the kernel leaves it zero, and
+    calls on one stream are ordered.  (Allocated on first use -- never inside a graph capture's first call of a stream.)"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    t = _MATCH_COUNTER_CACHE.get(key)
+    if t is None:
+        if len(_MATCH_COUNTER_CACHE) > 64:
+            _MATCH_COUNTER_CACHE.clear()
+        t = _MATCH_COUNTER_CACHE[key] = torch.zeros(MATCH_COUNTERS, dtype=torch.int32, device=device)
+    return t
+
+
 def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distance=False):
     """(Q,D), (G,D) same dtype (bf16 | f32), D % 64 == 0 -> (Q,k) int64 [+ (Q,k) f32 distances]."""
     _need_cuda(queries, gallery)
@@ -522,10 +550,15 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
         q_norms = row_norms(queries)
     if g_norms is None:
         g_norms = row_norms(gallery)
-    ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
     idx = torch.empty((qn, k), dtype=torch.int64, device=queries.device)
     dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
+    if USE_FUSED_MATCH and queries.dtype == BF16 and (qn + 255) // 256 <= MATCH_COUNTERS:
+        # one launch: GEMM on the LDS-ring kernel + per-tile top-k + merge by the last workgroup of a query tile
+        ws = torch.empty(lib.cvpce_match_fused_workspace_bytes(qn, gn, k), dtype=torch.uint8, device=queries.device)
+        T.match_topk_fused(queries, gallery, q_norms, g_norms, k, ws, _match_counters(queries.device), idx, dist)
+        return (idx, dist) if return_distance else idx
+    ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
     T.match_topk(queries, gallery, q_norms, g_norms, k, ws, idx, dist)
     return (idx, dist) if return_distance else idx
 

@@ -151,6 +151,21 @@ def _gln_transform(img, batch, index, h, w, mean, std):
              _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform')
 
 
+@_op('gln_transform_batch(Tensor[] imgs, Tensor(a!) batch, int[] h, int[] w, float[] mean, float[] std) -> ()')
+def _gln_transform_batch(imgs, batch, h, w, mean, std):
+    n, hp, wp, _ = batch.shape
+    if len(imgs) != n or len(h) != n or len(w) != n:
+        raise RuntimeError('gln_transform_batch: one image and one resized size per batch slot')
+    for t in imgs:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != 3:
+            raise RuntimeError('gln_transform_batch: images must be contiguous (3,H,W) float32 tensors')
+    ci = lambda v: (ctypes.c_int * n)(*[int(x) for x in v])
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in imgs])
+    fn = _by_dtype(batch, 'cvpce_gln_transform_batch', 'cvpce_gln_transform_batch_f16')
+    check(fn(ptrs, ci([t.shape[1] for t in imgs]), ci([t.shape[2] for t in imgs]), ci(h), ci(w), n, _p(batch), hp, wp,
+             _lib.float3(mean), _lib.float3(std), _stream()), 'gln_transform_batch')
+
+
 @_op('crop_resize(Tensor img, Tensor boxes, Tensor? count, Tensor(a!) out, int size, int mode, float[]? mean, float[]? std) -> ()')
 def _crop_resize(img, boxes, count, out, size, mode, mean, std):
     check(lib.cvpce_crop_resize(_p(img), _p(boxes), _p(count), boxes.shape[0], _p(out), img.shape[1], img.shape[2], size, mode,
@@ -213,6 +228,16 @@ def _match_topk(queries, gallery, q_norms, g_norms, k, workspace, idx, dist):
     check(lib.cvpce_match_topk(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), queries.shape[0], gallery.shape[0], queries.shape[1], k,
                                int(queries.dtype == torch.float32), _p(workspace), workspace.numel(), _p(idx), _p(dist), _stream()),
           'cvpce_match_topk')
+
+
+@_op('match_topk_fused(Tensor queries, Tensor gallery, Tensor q_norms, Tensor g_norms, int k, Tensor(a!) workspace, Tensor(b!) counters, '
+     'Tensor(c!) idx, Tensor(d!)? dist) -> ()')
+def _match_topk_fused(queries, gallery, q_norms, g_norms, k, workspace, counters, idx, dist):
+    if queries.dtype != torch.bfloat16 or gallery.dtype != torch.bfloat16 or counters.dtype != torch.int32:
+        raise RuntimeError('cvpce_match_topk_fused: bf16 rows, int32 counters')
+    check(lib.cvpce_match_topk_fused(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), queries.shape[0], gallery.shape[0], queries.shape[1], k,
+                                     _p(workspace), workspace.numel(), _p(counters), counters.numel(), _p(idx), _p(dist), _stream()),
+          'cvpce_match_topk_fused')
 
 
 @_op('probe_mfma_bf16(int shape, int iters, Tensor operands, Tensor(a!) sink, int workgroups) -> ()')

@@ -140,6 +140,11 @@ int cvpce_l2_normalize_f32(const float* in, float* out, void* out_bf16, int B, i
 int cvpce_gln_transform(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
                         const float* mean3, const float* std3, void* stream);
 
+/* The same for a whole batch in one launch: imgs / H0 / W0 / h / w are [host] arrays of n entries (read at the call), image i
+ * goes to slot i of out_nhwc8 [n][Hp][Wp][8].  Bit-identical to n calls of cvpce_gln_transform. */
+int cvpce_gln_transform_batch(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,
+                              void* out_nhwc8, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
+
 /* production.py:20 + datautils.py:234-239: crop boxes (xyxy f32, truncated like .to(long)) from the
  * original image, pad to square with 0.5, bilinear resize to SxS.  Boxes p >= *count_dev are skipped
  * (count_dev may be NULL).  mode 0: f32 NCHW in [0,1]; mode 1: NHWC8 bf16 with scale_to_tanh
@@ -206,6 +211,19 @@ int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int
 int cvpce_relu_f16(const void* in, void* out, long long n, void* stream);
 int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
                             const float* mean3, const float* std3, void* stream);
+int cvpce_gln_transform_batch_f16(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,
+                                  void* out_nhwc8, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
+
+/* The same result as cvpce_match_topk for bf16 rows, in ONE launch: the distance GEMM runs on the LDS-ring MFMA kernel
+ * (gallery rows = couts, queries = pixels; 256 x 256 tiles, or 64 gallery rows x 256 queries when Qn <= 256 so that one image's
+ * 200 proposals still spread over ~G/64 workgroups -- BASELINE configs[3]), the per-tile top-k is taken from the accumulators,
+ * and the last workgroup of a query tile (device-scope ticket in `counters`) merges the tiles' partials.  counters: device int
+ * array of n_counters >= ceil(Qn / 256) entries, ZERO on entry; the kernel leaves it zero again, so one persistent array per
+ * stream serves every call (calls that share the array must be ordered, e.g. on one stream). */
+size_t cvpce_match_fused_workspace_bytes(int Qn, int Gn, int k);
+int cvpce_match_topk_fused(const void* queries, const void* gallery, const float* q_norms, const float* g_norms, int Qn, int Gn,
+                           int D, int k, void* workspace, size_t workspace_bytes, int* counters, int n_counters,
+                           long long* out_idx, float* out_dist, void* stream);
 
 /* Calibration probe (not on the hot path; bench.py `measured_peaks`): a bare bf16 MFMA loop on register operands --
  * shape 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16; `workgroups` x 4 waves (one per SIMD) each issue

@@ -732,3 +732,20 @@ def test_bottleneck_fused_rejects_what_it_does_not_cover(cuda):
     assert not ops.can_fuse_bottleneck(x, mk(512, 2048, 1), mk(512, 512, 3), mk(2048, 512, 1), x)          # layer4: P = 512 does not fit the LDS
     x2 = torch.zeros(1, 8, 8, 256, dtype=BF, device=cuda)
     assert not ops.can_fuse_bottleneck(x2, mk(128, 256, 1), mk(128, 128, 3, 2), mk(512, 128, 1), torch.zeros(1, 4, 4, 512, dtype=BF, device=cuda))  # stride 2
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_transform_batch_equals_per_image(cuda, dtype):
+    """cvpce_gln_transform_batch: images of different sizes into one padded batch, bit-identical to the per-image launches."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    g = torch.Generator().manual_seed(12)
+    imgs = [torch.rand(3, h0, w0, generator=g).to(cuda) for h0, w0 in ((300, 517), (640, 480), (97, 131))] * 12     # 36 images: two launches
+    rs = [P.resized_hw(*i.shape[-2:]) for i in imgs]
+    hp, wp = max((r[0] + 31) // 32 * 32 for r in rs), max((r[1] + 31) // 32 * 32 for r in rs)
+    one = torch.full((len(imgs), hp, wp, 8), 3.0, dtype=dtype, device=cuda)
+    ops.gln_transform_batch(imgs, one, rs, P.IMAGE_MEAN, P.IMAGE_STD)
+    ref = torch.full((len(imgs), hp, wp, 8), 5.0, dtype=dtype, device=cuda)
+    for i, (img, (h, w)) in enumerate(zip(imgs, rs)):
+        ops.gln_transform_into(img, ref, i, h, w, P.IMAGE_MEAN, P.IMAGE_STD)
+    assert torch.equal(one, ref)
