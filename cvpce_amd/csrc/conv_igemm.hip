@@ -62,14 +62,6 @@ struct ConvArgs {
     int pool;
     int tiles_p, tiles_c;
     unsigned in_bytes, wgt_bytes;   // buffer-descriptor extents of `in` / `wgt` (LDS-DMA bounds check = zero fill)
-    // match epilogue (conv_dma16_kernel<..., EPI = 1>, csrc/match.hip): the GEMM is queries ("pixels", M of them) x gallery rows
-    // ("couts"); nothing is stored but the per-(query, cout tile) k smallest cosine distances, merged by the last workgroup of a
-    // query tile
-    const float* m_qn; const float* m_gn;       // row norms of queries / gallery (clamped at eps)
-    float* m_part_d; int* m_part_i;             // [M][tiles_c][k]
-    int* m_counter;                             // [tiles_p], zero on entry, zero again on exit
-    long long* m_out_idx; float* m_out_dist;    // [M][k]
-    int m_k;
 };
 
 // M index -> (image, oy, ox).  Row-major, or 2x2-quad order when the pool is fused.
@@ -636,148 +628,6 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma4_kernel(ConvArgs 
     conv_epilogue<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
-// lexicographic (d, i) < (e, j)
-__device__ __forceinline__ bool mlex_lt(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
-
-// Epilogue of the distance GEMM (cvpce_match_topk_fused; cvpce/models/classification.py:87-95): the accumulators hold
-// <query, gallery row>; per query the k smallest cosine distances of this cout tile (ties -> lower index) go to the partial
-// arrays, and the LAST workgroup of a query tile (device-scope counter) merges the partials of all cout tiles -- one launch
-// instead of GEMM + merge.  Accumulator layout (16x16x32): lane (lp = lane & 15, lq = lane >> 4) holds pixel lp of block nt
-// and couts 4 lq + {0..3} of block mt.
-template <int TC, int TP, int WC, int WP, int MT, int NT>
-__device__ __forceinline__ void match_epilogue16(const ConvArgs& a, f32x4 (&acc)[MT][NT], int tile_c, int tile_p, int wc, int wp,
-                                                 int lane, int tid, unsigned char* smem) {
-    constexpr int NW = WC * WP;
-    const int lp = lane & 15, lq = lane >> 4;
-    const int c_base = tile_c * TC + wc * (TC / WC), p_base = tile_p * TP + wp * (TP / WP);
-    float* cand_d = reinterpret_cast<float*>(smem);                 // [WC][TP]
-    int* cand_i = reinterpret_cast<int*>(smem + WC * TP * 4);       // [WC][TP]
-    int* s_last = reinterpret_cast<int*>(smem + 2 * WC * TP * 4);
-    // distances in place: d = 1 - <q, g> / (|q| |g|); rows past the gallery and NaNs (non-finite embeddings) sort last
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int q = p_base + nt * 16 + lp;
-        const float qn = (q < a.M) ? a.m_qn[q] : 1.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = c_base + mt * 16 + 4 * lq + j;
-                float d = INFINITY;
-                if (co < a.Cout) {
-                    d = 1.f - acc[mt][nt][j] / (qn * a.m_gn[co]);
-                    if (!(d == d)) d = INFINITY;
-                }
-                acc[mt][nt][j] = d;
-            }
-    }
-    __syncthreads();                    // every wave is done with the operand ring: the candidate arrays take its place
-    float pd[NT];
-    int pi[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { pd[nt] = -INFINITY; pi[nt] = -1; }
-    for (int r = 0; r < a.m_k; ++r) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float bd = INFINITY;
-            int bi = 0x7FFFFFFF;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int co = c_base + mt * 16 + 4 * lq + j;
-                    const float d = acc[mt][nt][j];
-                    if (mlex_lt(pd[nt], pi[nt], d, co) && mlex_lt(d, co, bd, bi)) { bd = d; bi = co; }
-                }
-#pragma unroll
-            for (int off = 16; off < 64; off <<= 1) {
-                const float od = __shfl_xor(bd, off);
-                const int oi = __shfl_xor(bi, off);
-                if (mlex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
-            }
-            if (lq == 0) {
-                const int pl = wp * (TP / WP) + nt * 16 + lp;
-                cand_d[wc * TP + pl] = bd;
-                cand_i[wc * TP + pl] = bi;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int pl = wp * (TP / WP) + nt * 16 + lp;
-            float bd = cand_d[pl];
-            int bi = cand_i[pl];
-#pragma unroll
-            for (int w = 1; w < WC; ++w) {
-                const float od = cand_d[w * TP + pl];
-                const int oi = cand_i[w * TP + pl];
-                if (mlex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
-            }
-            pd[nt] = bd; pi[nt] = bi;
-            const int q = p_base + nt * 16 + lp;
-            if (wc == 0 && lq == 0 && q < a.M) {
-                const size_t o = ((size_t)q * a.tiles_c + tile_c) * a.m_k + r;
-                a.m_part_d[o] = bd;
-                a.m_part_i[o] = bi;
-            }
-        }
-        __syncthreads();
-    }
-    // ---- the last workgroup of this query tile merges ----
-    __threadfence();                    // release: this workgroup's partials are visible device-wide before its ticket
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(a.m_counter + tile_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (ticket == a.tiles_c - 1);
-    }
-    __syncthreads();
-    if (!*s_last) return;
-    __threadfence();                    // acquire: the other workgroups' partials
-    const int n = a.tiles_c * a.m_k;
-    const int wid = tid >> 6;
-    for (int ql = wid; ql < TP; ql += NW) {          // one wave per query: entries over the lanes, k rounds of wave-wide lexicographic minimum
-        const int q = tile_p * TP + ql;
-        if (q >= a.M) break;
-        const float* d = a.m_part_d + (size_t)q * n;
-        const int* ix = a.m_part_i + (size_t)q * n;
-        constexpr int PER = 4;
-        float dv[PER];
-        int iv[PER];
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int j = e * 64 + lane;
-            dv[e] = (j < n) ? __hip_atomic_load(d + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
-            iv[e] = (j < n) ? __hip_atomic_load(ix + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7FFFFFFF;
-        }
-        float qd = -INFINITY;
-        int qi = -1;
-        for (int r = 0; r < a.m_k; ++r) {
-            float bd = INFINITY;
-            int bi = 0x7FFFFFFF;
-#pragma unroll
-            for (int e = 0; e < PER; ++e)
-                if (mlex_lt(qd, qi, dv[e], iv[e]) && mlex_lt(dv[e], iv[e], bd, bi)) { bd = dv[e]; bi = iv[e]; }
-            for (int j = PER * 64 + lane; j < n; j += 64) {
-                const float dj = __hip_atomic_load(d + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int ij = __hip_atomic_load(ix + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (mlex_lt(qd, qi, dj, ij) && mlex_lt(dj, ij, bd, bi)) { bd = dj; bi = ij; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(bd, off);
-                const int oi = __shfl_xor(bi, off);
-                if (mlex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
-            }
-            if (lane == 0) {
-                a.m_out_idx[(size_t)q * a.m_k + r] = (long long)bi;
-                if (a.m_out_dist) a.m_out_dist[(size_t)q * a.m_k + r] = bd;
-            }
-            qd = bd; qi = bi;
-        }
-    }
-    if (tid == 0) __hip_atomic_store(a.m_counter + tile_p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-}
-
 // ===========================================================================
 // LDS-DMA kernel, 4-stage ring, v_mfma_f32_16x16x32_bf16 variant
 // ===========================================================================
@@ -792,7 +642,7 @@ __device__ __forceinline__ void match_epilogue16(const ConvArgs& a, f32x4 (&acc)
 // K-steps (4 x 32 KiB at 256x256): stage t+3 is issued while stage t computes, the wave waits with
 // a COUNTED vmcnt (never 0 in steady state) and a raw s_barrier (a __syncthreads() would drain
 // vmcnt to 0).  K order: (64-channel chunk, kh, kw, 32-channel half, channel).
-template <typename E, int TC, int TP, int WC, int WP, int MINW, int NS, int EPI = 0>
+template <typename E, int TC, int TP, int WC, int WP, int MINW, int NS>
 __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs a) {
     constexpr int BK = 32;
     static_assert(NS == 3 || NS == 4, "ring depth");
@@ -976,10 +826,7 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs
 #undef CVPCE_READ_B
 #undef CVPCE_MFMAS
 #undef CVPCE_DMA4_STAGE
-    if constexpr (EPI == 1)
-        match_epilogue16<TC, TP, WC, WP, MT, NT>(a, acc, tile_c, tile_p, wc, wp, lane, tid, smem);
-    else
-        conv_epilogue16<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
+    conv_epilogue16<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
 // ===========================================================================
@@ -1253,53 +1100,3 @@ extern "C" int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const floa
     return conv2d_dispatch<ElemF16>(CVPCE_CONV2D_ARGS);
 }
 #undef CVPCE_CONV2D_ARGS
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Distance GEMM with fused top-k (bf16): queries x gallery as a 1x1 "convolution" of the LDS-ring kernel -- gallery rows are
-// the couts, queries the pixels -- with match_epilogue16 instead of a store.  Two tilings: 256 x 256 (8 waves; MFMA-bound
-// batches of queries) and 64 gallery rows x 256 queries (4 waves; one image's worth of queries: as many workgroups as the
-// gallery allows, the launch is latency-bound).
-template <int TC, int TP, int WC, int WP>
-static int launch_match16(ConvArgs a, hipStream_t stream) {
-    a.tiles_p = (a.M + TP - 1) / TP;
-    a.tiles_c = (a.Cout + TC - 1) / TC;
-    const size_t smem = (size_t)4 * (TC + TP) * 32 * sizeof(bf16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma16_kernel<ElemBF16, TC, TP, WC, WP, 2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv_dma16_kernel<ElemBF16, TC, TP, WC, WP, 2, 4, 1>), dim3(a.tiles_p * a.tiles_c), dim3(WC * WP * 64), smem, stream, a);
-    return cvpce_check_launch();
-}
-
-extern "C" size_t cvpce_match_fused_workspace_bytes(int Qn, int Gn, int k) {
-    const size_t tiles = ((size_t)Gn + 63) / 64;          // the finer of the two cout tilings
-    return (size_t)Qn * tiles * k * 8 + 512;
-}
-
-extern "C" int cvpce_match_topk_fused(const void* queries, const void* gallery, const float* q_norms, const float* g_norms, int Qn, int Gn,
-                                      int D, int k, void* workspace, size_t workspace_bytes, int* counters, int n_counters,
-                                      long long* out_idx, float* out_dist, void* stream) {
-    if (!queries || !gallery || !q_norms || !g_norms || !workspace || !counters || !out_idx) return CVPCE_ERR_ARG;
-    if (D <= 0 || D % 64 != 0 || k < 1 || k > 16 || Gn < k) return CVPCE_ERR_ARG;
-    if (Qn <= 0) return CVPCE_OK;
-    if (workspace_bytes < cvpce_match_fused_workspace_bytes(Qn, Gn, k) || n_counters < (Qn + 255) / 256) return CVPCE_ERR_ARG;
-    if (((unsigned long long)Gn + 256) * D * 2 >= (1ull << 32) || ((unsigned long long)Qn + 256) * D * 2 >= (1ull << 32)) return CVPCE_ERR_ARG;
-    ConvArgs a;
-    a.in = (const bf16_t*)queries; a.wgt = (const bf16_t*)gallery; a.bias = nullptr; a.res = nullptr; a.out = nullptr;
-    a.N = 1; a.H = 1; a.W = Qn; a.Cin = D; a.Cout = Gn; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.Ho = 1; a.Wo = Qn;
-    a.K_pad = D; a.M = Qn; a.relu = 0; a.out_f32 = 0; a.in_up_shift = 0; a.res_mode = 0; a.Hr = 0; a.Wr = 0; a.pool = 0;
-    a.tiles_p = a.tiles_c = 0;
-    a.in_bytes = (unsigned)((long long)Qn * D * 2);
-    a.wgt_bytes = (unsigned)((long long)Gn * D * 2);       // rows past the gallery read as zeros (and are masked by co < Cout)
-    a.m_qn = q_norms; a.m_gn = g_norms; a.m_k = k;
-    const size_t tiles = ((size_t)Gn + 63) / 64;
-    a.m_part_d = (float*)workspace;
-    a.m_part_i = (int*)((char*)workspace + ((size_t)Qn * tiles * k * 4 + 255) / 256 * 256);
-    a.m_counter = counters; a.m_out_idx = out_idx; a.m_out_dist = out_dist;
-    hipStream_t s = (hipStream_t)stream;
-    return Qn > 256 ? launch_match16<256, 256, 2, 4>(a, s) : launch_match16<64, 256, 1, 4>(a, s);
-}

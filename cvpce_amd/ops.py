@@ -518,23 +518,6 @@ def row_norms(x, eps=1e-8):
     return out
 
 
-USE_FUSED_MATCH = _os.environ.get('CVPCE_FUSED_MATCH', '1') != '0'   # A/B switch: bf16 matcher as ONE launch (cvpce_match_topk_fused)
-MATCH_COUNTERS = 64                 # query tiles of 256 a call may have (16 384 queries); more -> the two-launch kernels
-_MATCH_COUNTER_CACHE = {}
-
-
-def _match_counters(device):
-    """The zero-initialised ticket array of cvpce_match_topk_fused, one per (device, stream): the kernel leaves it zero, and
-    calls on one stream are ordered.  (Allocated on first use -- never inside a graph capture's first call of a stream.)"""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    t = _MATCH_COUNTER_CACHE.get(key)
-    if t is None:
-        if len(_MATCH_COUNTER_CACHE) > 64:
-            _MATCH_COUNTER_CACHE.clear()
-        t = _MATCH_COUNTER_CACHE[key] = torch.zeros(MATCH_COUNTERS, dtype=torch.int32, device=device)
-    return t
-
-
 def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distance=False):
     """(Q,D), (G,D) same dtype (bf16 | f32), D % 64 == 0 -> (Q,k) int64 [+ (Q,k) f32 distances]."""
     _need_cuda(queries, gallery)
@@ -552,11 +535,6 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
         g_norms = row_norms(gallery)
     idx = torch.empty((qn, k), dtype=torch.int64, device=queries.device)
     dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
-    if USE_FUSED_MATCH and queries.dtype == BF16 and (qn + 255) // 256 <= MATCH_COUNTERS:
-        # one launch: GEMM on the LDS-ring kernel + per-tile top-k + merge by the last workgroup of a query tile
-        ws = torch.empty(lib.cvpce_match_fused_workspace_bytes(qn, gn, k), dtype=torch.uint8, device=queries.device)
-        T.match_topk_fused(queries, gallery, q_norms, g_norms, k, ws, _match_counters(queries.device), idx, dist)
-        return (idx, dist) if return_distance else idx
     ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
     T.match_topk(queries, gallery, q_norms, g_norms, k, ws, idx, dist)

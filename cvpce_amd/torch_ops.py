@@ -230,16 +230,6 @@ def _match_topk(queries, gallery, q_norms, g_norms, k, workspace, idx, dist):
           'cvpce_match_topk')
 
 
-@_op('match_topk_fused(Tensor queries, Tensor gallery, Tensor q_norms, Tensor g_norms, int k, Tensor(a!) workspace, Tensor(b!) counters, '
-     'Tensor(c!) idx, Tensor(d!)? dist) -> ()')
-def _match_topk_fused(queries, gallery, q_norms, g_norms, k, workspace, counters, idx, dist):
-    if queries.dtype != torch.bfloat16 or gallery.dtype != torch.bfloat16 or counters.dtype != torch.int32:
-        raise RuntimeError('cvpce_match_topk_fused: bf16 rows, int32 counters')
-    check(lib.cvpce_match_topk_fused(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), queries.shape[0], gallery.shape[0], queries.shape[1], k,
-                                     _p(workspace), workspace.numel(), _p(counters), counters.numel(), _p(idx), _p(dist), _stream()),
-          'cvpce_match_topk_fused')
-
-
 @_op('probe_mfma_bf16(int shape, int iters, Tensor operands, Tensor(a!) sink, int workgroups) -> ()')
 def _probe_mfma_bf16(shape, iters, operands, sink, workgroups):
     check(lib.cvpce_probe_mfma_bf16(shape, iters, _p(operands), _p(sink), workgroups, _stream()), 'probe')

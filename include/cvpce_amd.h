@@ -214,17 +214,6 @@ int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, i
 int cvpce_gln_transform_batch_f16(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,
                                   void* out_nhwc8, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
 
-/* The same result as cvpce_match_topk for bf16 rows, in ONE launch: the distance GEMM runs on the LDS-ring MFMA kernel
- * (gallery rows = couts, queries = pixels; 256 x 256 tiles, or 64 gallery rows x 256 queries when Qn <= 256 so that one image's
- * 200 proposals still spread over ~G/64 workgroups -- BASELINE configs[3]), the per-tile top-k is taken from the accumulators,
- * and the last workgroup of a query tile (device-scope ticket in `counters`) merges the tiles' partials.  counters: device int
- * array of n_counters >= ceil(Qn / 256) entries, ZERO on entry; the kernel leaves it zero again, so one persistent array per
- * stream serves every call (calls that share the array must be ordered, e.g. on one stream). */
-size_t cvpce_match_fused_workspace_bytes(int Qn, int Gn, int k);
-int cvpce_match_topk_fused(const void* queries, const void* gallery, const float* q_norms, const float* g_norms, int Qn, int Gn,
-                           int D, int k, void* workspace, size_t workspace_bytes, int* counters, int n_counters,
-                           long long* out_idx, float* out_dist, void* stream);
-
 /* Calibration probe (not on the hot path; bench.py `measured_peaks`): a bare bf16 MFMA loop on register operands --
  * shape 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16; `workgroups` x 4 waves (one per SIMD) each issue
  * iters x 16 MFMAs on 4 x 4 independent accumulators.  operands: >= 128 KiB of random bf16; sink: workgroups * 256 floats.
