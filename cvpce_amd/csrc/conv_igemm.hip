@@ -1034,6 +1034,13 @@ static int launch_conv_dma16(const ConvArgs& a0, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
+#include <stdlib.h>
+// dev A/B switch (environment, read once): CVPCE_NO_TC32=1 sends thin outputs through the 64-cout tile as before round 3
+static bool use_tc32() {
+    static const bool on = !(getenv("CVPCE_NO_TC32") && getenv("CVPCE_NO_TC32")[0] == '1');
+    return on;
+}
+
 template <typename E>
 static int conv2d_dispatch(const void* in, const void* wgt, const float* bias, const void* res,
                            void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -1078,6 +1085,10 @@ static int conv2d_dispatch(const void* in, const void* wgt, const float* bias, c
     }
     if (Cout > 64) {
         return bk64 ? launch_conv<E, 128, 128, 64, 2, 2>(a, s) : launch_conv<E, 128, 128, 32, 2, 2>(a, s);
+    } else if (Cout <= 32 && bk64 && use_tc32()) {
+        // thin outputs on wide inputs (cls_logits 256 -> 9, the Gaussian subnet's 64 -> 32): a 32-cout tile halves the MFMA work spent
+        // on cout padding (with K-step 32 a 32-row weight tile is less than one staging pass of the 256 threads: not instantiated)
+        return launch_conv<E, 32, 128, 64, 1, 4>(a, s);
     } else {
         return bk64 ? launch_conv<E, 64, 128, 64, 2, 2>(a, s) : launch_conv<E, 64, 128, 32, 2, 2>(a, s);
     }

@@ -105,8 +105,8 @@ class ConvProfile:
                 return 'conv_dma_kernel<128,128,2,2,2>'
             if 32 < pc.cout <= 64 and tiles256 >= 128:
                 return 'conv_dma_kernel<64,128,2,2,2>'
-        tc = 128 if pc.cout > 64 else 64
-        return f'conv_igemm_kernel<{tc},128,{64 if bk64 else 32},2,2>'
+        tc = 128 if pc.cout > 64 else (32 if (pc.cout <= 32 and bk64) else 64)
+        return f'conv_igemm_kernel<{tc},128,{64 if bk64 else 32},{1 if tc == 32 else 2},{4 if tc == 32 else 2}>'
 
     def summary(self):
         torch.cuda.synchronize()

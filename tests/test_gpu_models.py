@@ -551,3 +551,25 @@ def test_classifier_classify_matches_reference_fixture(cuda, golden_dir, match_d
         assert emb.shape == case['embedding'].shape
         if case['n']:
             assert (emb.cpu() - case['embedding']).abs().max() < 5e-3      # bf16 rounding of the packed input
+
+
+def test_proposal_generator_single_sync_path_equals_generic(cuda, gln_model):
+    """ProposalGenerator.generate_proposals_and_images (production.py:16-20): the engine path (confidence prefix + degenerate-box
+    test from ONE device-to-host copy) returns exactly what the reference-shaped generic path (boolean masks over the detector's
+    result dict) returns -- including an image whose confident boxes contain degenerate ones."""
+    from cvpce_amd import production, synthetic
+    det, _ = gln_model
+
+    class Plain:                       # the same detector without `.engine`: forces the generic path
+        def __init__(self, d):
+            self.d = d
+
+        def __call__(self, x):
+            return self.d(x)
+
+    for seed, size in ((3, (512, 640)), (4, (96, 96))):          # 96 x 96: tiny boxes, some collapse under .to(long)
+        img = synthetic.shelf_image(seed, *size).to(cuda)
+        fast = production.ProposalGenerator(det, device=cuda, confidence_threshold=0.5).generate_proposals_and_images(img)
+        slow = production.ProposalGenerator(Plain(det), device=cuda, confidence_threshold=0.5).generate_proposals_and_images(img)
+        assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+        assert len(fast[0]) > 0
