@@ -142,7 +142,10 @@ def measured_peaks(dev):
     del src, dst
     m32 = ops.probe_mfma_bf16(0, seconds=2.0)
     m16 = ops.probe_mfma_bf16(1, seconds=2.0)
+    l2 = {f'{mib}MiB': round(ops.probe_l2_stream(mib, seconds=0.5), 2) for mib in (1, 2, 16)}
     return {'library_gemm_bf16_tflops': round(gemm, 1), 'device_copy_gbs': round(copy, 1),
+            'l2_stream_to_registers_tbs': dict(l2, note='every workgroup walks the same buffer with 16-byte buffer loads (csrc/probe.hip): '
+                                                        '1-2 MiB = a layer\'s weights resident in each XCD\'s L2, 16 MiB = beyond it'),
             'bare_mfma_loop_tflops': {'32x32x16': round(m32, 1), '16x16x32': round(m16, 1),
                                       'note': 'register operands, random data, one wave per SIMD, >= 2 s back to back (csrc/probe.hip)'},
             'nominal': {'mfma_bf16_dense_tflops': MFMA_BF16_DENSE_PEAK_TFLOPS, 'hbm_gbs': HBM_PEAK_GBS}}

@@ -79,3 +79,29 @@ extern "C" int cvpce_probe_mfma_bf16(int shape, int iters, const void* operands,
         hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3(workgroups), dim3(256), 96 * 1024, (hipStream_t)stream, (const bf16_t*)operands, sink, iters);
     return cvpce_check_launch();
 }
+
+// Second calibration probe: how fast the CUs can stream an L2-resident operand into registers -- the way the halo kernels read
+// their weights (buffer_load_dwordx4, every workgroup walks the SAME `bytes`-long buffer `iters` times, 8 loads in flight per
+// lane).  bytes <= 4 MiB stays in each XCD's L2; the result bounds every design that re-streams weights per pixel tile (the
+// Winograd F(2x2,3x3) study of DESIGN.md needs 4x the weight bytes per MFMA FLOP of the direct kernel).
+__global__ __launch_bounds__(512, 2) void l2_stream_probe_kernel(const u32x4* __restrict__ buf, unsigned n16, int iters, float* __restrict__ sink) {
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, n16 * 16u, 0x00020000);
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    for (int it = 0; it < iters; ++it) {
+        for (unsigned base = threadIdx.x; base + 7u * 512u < n16; base += 8u * 512u) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(srd, (base + (unsigned)u * 512u) * 16u, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+        asm volatile("" : "+v"(acc));     // the next walk is not merged with this one
+    }
+    sink[(size_t)blockIdx.x * 512 + threadIdx.x] = __uint_as_float(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+}
+
+extern "C" int cvpce_probe_l2_stream(const void* buf, long long bytes, int iters, float* sink, int workgroups, void* stream) {
+    if (!buf || !sink || iters < 1 || workgroups < 1 || bytes < 8 * 512 * 16 || bytes % (8 * 512 * 16) != 0 || bytes >= (1LL << 32)) return CVPCE_ERR_ARG;
+    hipLaunchKernelGGL(l2_stream_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (const u32x4*)buf, (unsigned)(bytes / 16), iters, sink);
+    return cvpce_check_launch();
+}

@@ -577,3 +577,24 @@ def probe_mfma_bf16(shape, seconds=2.0, iters=20000, workgroups=256):
         if time.perf_counter() - t0 >= seconds:
             break
     return last        # the rate of the LAST group of launches: the settled clock, not the cold-start burst
+
+
+def probe_l2_stream(mib=2, seconds=1.0, workgroups=512, iters=64):
+    """TB/s at which all CUs together stream one L2-resident buffer of `mib` MiB into registers (csrc/probe.hip)."""
+    import time
+    dev = torch.device('cuda', torch.cuda.current_device())
+    buf = torch.randint(0, 1 << 30, (mib << 18,), dtype=torch.int32, device=dev)
+    sink = torch.empty(workgroups * 512, dtype=torch.float32, device=dev)
+    T.probe_l2_stream(buf, 2, sink, workgroups)
+    torch.cuda.synchronize()
+    t0, last = time.perf_counter(), 0.0
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        T.probe_l2_stream(buf, iters, sink, workgroups)
+        e1.record()
+        torch.cuda.synchronize()
+        last = workgroups * iters * (mib << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        if time.perf_counter() - t0 >= seconds:
+            break
+    return last

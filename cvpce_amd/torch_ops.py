@@ -235,4 +235,9 @@ def _probe_mfma_bf16(shape, iters, operands, sink, workgroups):
     check(lib.cvpce_probe_mfma_bf16(shape, iters, _p(operands), _p(sink), workgroups, _stream()), 'probe')
 
 
+@_op('probe_l2_stream(Tensor buf, int iters, Tensor(a!) sink, int workgroups) -> ()')
+def _probe_l2_stream(buf, iters, sink, workgroups):
+    check(lib.cvpce_probe_l2_stream(_p(buf), buf.numel() * buf.element_size(), iters, _p(sink), workgroups, _stream()), 'probe_l2_stream')
+
+
 T = torch.ops.cvpce_amd

@@ -220,6 +220,11 @@ int cvpce_gln_transform_batch_f16(const float* const* imgs, const int* H0, const
  * FLOPs = workgroups * 4 * iters * 16 * F with F = 2*32*32*16 = 32768 per MFMA for shape 0 and 2*16*16*32 = 16384 for shape 1. */
 int cvpce_probe_mfma_bf16(int shape, int iters, const void* operands, float* sink, int workgroups, void* stream);
 
+/* Calibration probe (bench.py `measured_peaks`): `workgroups` x 512 threads each walk the same L2-resident buffer (bytes: a
+ * multiple of 64 KiB, < 4 GiB) `iters` times with 16-byte buffer loads, 8 in flight per lane -- the rate at which the halo
+ * kernels can stream weights from L2 into registers.  Bytes moved = workgroups * iters * bytes.  sink: workgroups * 512 floats. */
+int cvpce_probe_l2_stream(const void* buf, long long bytes, int iters, float* sink, int workgroups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
