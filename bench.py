@@ -51,6 +51,7 @@ def parse():
                     help="storage type of the detector's weights / activations: bf16 (default, what BASELINE's configs name) or the fp16 accuracy mode")
     ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; value = the median window')
     ap.add_argument('--no-workloads', action='store_true', help='skip the configs[1] / configs[3] figures appended to the pipeline line')
+    ap.add_argument('--no-overlap', action='store_true', help='A/B switch: detector and embedder of consecutive steps strictly one after the other')
     ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -257,7 +258,7 @@ def run_h2d_leg(pipe, host_images, dev, steps, warmup):
         b = s % 2
         upload(1 - b)                                   # next batch: overlaps with this step's kernels
         main.wait_event(ready[b])
-        pipe.run(bufs[b])
+        pipe.run(bufs[b], inputs_ready=ready[b])        # the detector's own stream waits for the upload itself, not for the previous step
         free[b].record(main)
 
     upload(0)
@@ -295,7 +296,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     mdt = torch.bfloat16 if args.match_dtype == 'bf16' else torch.float32
     clf = production.Classifier.from_embedding(enc, gallery, [f'sku_{i:05d}' for i in range(args.gallery)],
                                                device=dev, emb_device=dev, k=1, match_dtype=mdt)
-    pipe = production.BatchedPipeline(det, clf, 0.5)
+    pipe = production.BatchedPipeline(det, clf, 0.5, overlap_detector=not args.no_overlap)
 
     # images are identified by their GLOBAL index in the job's batch of world * ipg images (contiguous blocks per rank,
     # cvpce_amd.dist.shard_images): image g is the same tensor whatever the world size
@@ -307,7 +308,8 @@ def run_pipeline(args, rank, local_rank, world, dev):
     outs = [None]
 
     def step():
-        outs[0] = pipe.run(images)
+        # inputs resident and complete before the timed region: the detector of step i + 1 may start beside the embedder of step i
+        outs[0] = pipe.run(images, inputs_ready=True)
 
     for _ in range(args.warmup):
         step()
@@ -393,7 +395,9 @@ def run_pipeline(args, rank, local_rank, world, dev):
                                f'(SKU-110K shape) -> GLN detect (800x800 internal, detections_per_img={dpi}, conf>0.5) -> RoI crop 256x256 '
                                f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
                    'images_per_gpu': ipg, 'global_images': world * ipg, 'proposals_per_image': proposals, 'gallery': args.gallery,
-                   'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision, 'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
+                   'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision,
+                   'stage_overlap': 'none' if args.no_overlap else 'detector of step i+1 on its own stream beside the embedder of step i',
+                   'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
                    'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
                    'gallery_build_s': round(t_gallery, 3), 'collectives': cdist.backend_name()},
     }
