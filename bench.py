@@ -51,7 +51,6 @@ def parse():
                     help="storage type of the detector's weights / activations: bf16 (default, what BASELINE's configs name) or the fp16 accuracy mode")
     ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; value = the median window')
     ap.add_argument('--no-workloads', action='store_true', help='skip the configs[1] / configs[3] figures appended to the pipeline line')
-    ap.add_argument('--xcd-partition', action='store_true', help='detector on one XCD (32 CUs), crop + embedder + matcher on the other seven (CU-masked streams)')
     ap.add_argument('--no-overlap', action='store_true', help='A/B switch: detector and embedder of consecutive steps strictly one after the other')
     ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -297,7 +296,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     mdt = torch.bfloat16 if args.match_dtype == 'bf16' else torch.float32
     clf = production.Classifier.from_embedding(enc, gallery, [f'sku_{i:05d}' for i in range(args.gallery)],
                                                device=dev, emb_device=dev, k=1, match_dtype=mdt)
-    pipe = production.BatchedPipeline(det, clf, 0.5, overlap_detector=not args.no_overlap, xcd_partition=args.xcd_partition and not args.no_overlap)
+    pipe = production.BatchedPipeline(det, clf, 0.5, overlap_detector=not args.no_overlap)
 
     # images are identified by their GLOBAL index in the job's batch of world * ipg images (contiguous blocks per rank,
     # cvpce_amd.dist.shard_images): image g is the same tensor whatever the world size
@@ -402,8 +401,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
                                f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
                    'images_per_gpu': ipg, 'global_images': world * ipg, 'proposals_per_image': proposals, 'gallery': args.gallery,
                    'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision,
-                   'stage_overlap': 'none' if args.no_overlap else ('detector of step i+1 on its own stream beside the embedder of step i'
-                                                                   + (', on disjoint CUs: detector 1 XCD (32 CUs), crop + embed + match 7 XCDs (224 CUs)' if args.xcd_partition else '')),
+                   'stage_overlap': 'none' if args.no_overlap else 'detector of step i+1 queued on its own stream beside the embedder of step i',
                    'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
                    'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
                    'gallery_build_s': round(t_gallery, 3), 'collectives': cdist.backend_name()},

@@ -32,7 +32,7 @@ ASPECT_RATIOS = (0.5, 1.0, 2.0)
 FPN_CHANNELS = 256
 USE_HEAD_ATLAS = True   # head towers on ONE atlas of the 5 pyramid levels (one launch per tower layer) instead of per level
 N_SIDE_STREAMS = 4   # head towers of the 5 levels run concurrently on side HIP streams (0 = everything on one stream)
-USE_DETECT_GRAPH = True   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
+USE_DETECT_GRAPH = os.environ.get('CVPCE_DETECT_GRAPH', '1') != '0'   # replay the static launch schedule of a batch shape from a hipGraph (captured on the shape's 2nd call)
 MAX_DETECT_GRAPHS = 4     # batch shapes kept captured (each graph keeps its intermediates alive: ~0.4 GB per 2048^2 image); LRU
 CAPTURE_ON_SIGHT = 2      # a geometry is captured on its 2nd call (the 1st runs eagerly and fills the host-side caches) ...
 MAX_CAPTURE_ON_SIGHT = 16  # ... and later, up to this many sights, once captured graphs start being evicted barely used (many geometries)

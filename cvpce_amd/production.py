@@ -275,37 +275,18 @@ class BatchedPipeline:
     NHWC bf16 embedder input (no f32 crop tensor, no host round trip), one distance GEMM per batch.
     """
 
-    def __init__(self, detector, classifier, confidence_threshold=0.5, overlap_detector=True, xcd_partition=False):
+    def __init__(self, detector, classifier, confidence_threshold=0.5, overlap_detector=True):
         """overlap_detector: run the detector of a call on its own (high-priority) HIP stream, so that -- when the caller says
-        its images are ready (`run(..., inputs_ready=True)` or passes their ready event) -- the detector of call i + 1 runs BESIDE
-        the embedder of call i instead of behind it.  Same kernels, same results; only the order in which the two stages'
-        launches reach the chip changes.
-
-        xcd_partition (with overlap_detector): the two stages get disjoint parts of the chip through CU-masked streams
-        (hipExtStreamCreateWithCUMask): the detector one XCD (32 CUs, its own L2), crop + embedder + matcher the other seven
-        (224 CUs).  The detector is a chain of ~150 short latency-bound launches that takes the same 5.2 ms on 32 CUs as on 256
-        (tools/cu_mask_probe.py), while the embedder's persistent kernels lose only 6 % on 7/8 of the CUs (the chip is
-        power-limited: fewer busy CUs clock higher) -- side by side they finish a step sooner than one after the other.  The
-        persistent kernels' grid bound is PROCESS-wide (cvpce_set_persistent_workgroups): it is set to 224 here."""
+        its images are ready (`run(..., inputs_ready=True)` or passes their ready event) -- the detector of call i + 1 is queued
+        BESIDE the embedder of call i instead of behind it.  Same kernels, same results; only the order in which the two stages'
+        launches reach the chip changes.  (Measured gain: 1.3 % -- the embedder's persistent kernels hold every CU, so the
+        detector only gets the tails of their launches; giving the detector its own XCD through CU-masked streams was measured
+        and rejected: profiles/r03_rejected_experiments.md.)"""
         self.detector = detector
         self.classifier = classifier
         self.confidence_threshold = confidence_threshold
         self.overlap_detector = overlap_detector
-        self.xcd_partition = bool(xcd_partition and overlap_detector)
         self._det_stream = None
-        self._work_stream = None
-
-    def _streams(self, device):
-        """(detector stream, stream of crop / embed / match or None = the caller's current stream), created on first use."""
-        if self._det_stream is None:
-            if self.xcd_partition:
-                # CU-mask bit i selects a CU of XCD i % 8 (MI355X: 8 XCDs x 32 CUs): bits = 7 (mod 8) are one whole XCD
-                det_bits = {i for i in range(256) if i % 8 == 7}
-                self._det_stream = _masked_stream(det_bits)
-                self._work_stream = _masked_stream(set(range(256)) - det_bits)
-            else:
-                self._det_stream = torch.cuda.Stream(device=device, priority=-1)
-        return self._det_stream, self._work_stream
 
     def _crops(self, images, det_out):
         """RoI crops of every image's confident boxes, launched WITHOUT knowing the counts on the host: the crop kernel reads
@@ -375,15 +356,12 @@ class BatchedPipeline:
         pin = self.__dict__.setdefault('_count_pins', {})
         if n not in pin:
             pin[n] = torch.empty(n, dtype=torch.int32).pin_memory()
-        caller = torch.cuda.current_stream()
-        side = work = None
+        main = torch.cuda.current_stream()
+        side = None
         if self.overlap_detector and stage_events is None:
-            side, work = self._streams(det.engine().device)
-        if self.xcd_partition:
-            # grid bound of the persistent conv kernels = the CUs their stream may use (process-wide; read at launch time):
-            # 224 on the masked stream, the whole chip when this call runs un-partitioned (stage timing)
-            from ._lib import lib, check
-            check(lib.cvpce_set_persistent_workgroups(224 if work is not None else 256), 'cvpce_set_persistent_workgroups')
+            if self._det_stream is None:
+                self._det_stream = torch.cuda.Stream(device=det.engine().device, priority=-1)
+            side = self._det_stream
         t0 = mark()
         # The one host synchronisation of a step -- the confidence-prefix counts, which size the embedder's batch -- is
         # taken BESIDE the crop kernels, not before them: the counts go to pinned host memory right behind the detector,
@@ -395,20 +373,13 @@ class BatchedPipeline:
             pin[n].copy_(det_out[4], non_blocking=True)
             copied = torch.cuda.Event()
             copied.record()
-            main = caller
         else:
-            main = work if work is not None else caller
             if isinstance(inputs_ready, torch.cuda.Event):
-                ready = inputs_ready
+                side.wait_event(inputs_ready)
             elif not inputs_ready:
                 ready = torch.cuda.Event()
-                ready.record(caller)
-            else:
-                ready = None
-            if ready is not None:
+                ready.record(main)
                 side.wait_event(ready)
-                if main is not caller:
-                    main.wait_event(ready)
             with torch.cuda.stream(side):
                 det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
                 pin[n].copy_(det_out[4], non_blocking=True)
@@ -418,36 +389,15 @@ class BatchedPipeline:
                 t.record_stream(main)          # allocated on the detector stream, consumed on the embedder's
             main.wait_event(copied)
             t1 = None
-        with torch.cuda.stream(main):
-            crops = self._crops(images, det_out)
-            copied.synchronize()
-            counts = pin[n].tolist()
-            valid, sel = self._select(crops, counts)
-            t2 = mark()
-            emb = self.classifier.encoder.engine().embed_packed(valid)
-            t3 = mark()
-            idx = self.classifier.match(emb)
-            t4 = mark()
-            if stage_events is not None:
-                stage_events += [('detect', t0, t1), ('crop', t1, t2), ('embed', t2, t3), ('match', t3, t4)]
-            out = self._finish(images, det_out, counts, emb, idx, sel)
-        if main is not caller:
-            # results were produced on the masked stream: whatever the caller queues next on ITS stream sees them complete
-            done = torch.cuda.Event()
-            done.record(main)
-            caller.wait_event(done)
-            for t in list(det_out) + [v for v in out.values() if torch.is_tensor(v)]:
-                t.record_stream(caller)
-        return out
-
-
-def _masked_stream(cu_bits):
-    """A HIP stream whose kernels run only on the CUs whose bit is set (hipExtStreamCreateWithCUMask), as a torch stream."""
-    import ctypes
-    hip = ctypes.CDLL('libamdhip64.so')
-    words = (ctypes.c_uint32 * 8)(*[sum(1 << b for b in range(32) if (32 * w + b) in cu_bits) for w in range(8)])
-    st = ctypes.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-    if rc != 0:
-        raise RuntimeError(f'hipExtStreamCreateWithCUMask failed: {rc}')
-    return torch.cuda.ExternalStream(st.value)
+        crops = self._crops(images, det_out)
+        copied.synchronize()
+        counts = pin[n].tolist()
+        valid, sel = self._select(crops, counts)
+        t2 = mark()
+        emb = self.classifier.encoder.engine().embed_packed(valid)
+        t3 = mark()
+        idx = self.classifier.match(emb)
+        t4 = mark()
+        if stage_events is not None:
+            stage_events += [('detect', t0, t1), ('crop', t1, t2), ('embed', t2, t3), ('match', t3, t4)]
+        return self._finish(images, det_out, counts, emb, idx, sel)
