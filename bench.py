@@ -51,7 +51,6 @@ def parse():
                     help="storage type of the detector's weights / activations: bf16 (default, what BASELINE's configs name) or the fp16 accuracy mode")
     ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; value = the median window')
     ap.add_argument('--no-workloads', action='store_true', help='skip the configs[1] / configs[3] figures appended to the pipeline line')
-    ap.add_argument('--no-overlap', action='store_true', help='A/B switch: detector and embedder of consecutive steps strictly one after the other')
     ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -258,7 +257,7 @@ def run_h2d_leg(pipe, host_images, dev, steps, warmup):
         b = s % 2
         upload(1 - b)                                   # next batch: overlaps with this step's kernels
         main.wait_event(ready[b])
-        pipe.run(bufs[b], inputs_ready=ready[b])        # the detector's own stream waits for the upload itself, not for the previous step
+        pipe.run(bufs[b])
         free[b].record(main)
 
     upload(0)
@@ -296,7 +295,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     mdt = torch.bfloat16 if args.match_dtype == 'bf16' else torch.float32
     clf = production.Classifier.from_embedding(enc, gallery, [f'sku_{i:05d}' for i in range(args.gallery)],
                                                device=dev, emb_device=dev, k=1, match_dtype=mdt)
-    pipe = production.BatchedPipeline(det, clf, 0.5, overlap_detector=not args.no_overlap)
+    pipe = production.BatchedPipeline(det, clf, 0.5)
 
     # images are identified by their GLOBAL index in the job's batch of world * ipg images (contiguous blocks per rank,
     # cvpce_amd.dist.shard_images): image g is the same tensor whatever the world size
@@ -308,8 +307,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     outs = [None]
 
     def step():
-        # inputs resident and complete before the timed region: the detector of step i + 1 may start beside the embedder of step i
-        outs[0] = pipe.run(images, inputs_ready=True)
+        outs[0] = pipe.run(images)
 
     for _ in range(args.warmup):
         step()
@@ -336,10 +334,6 @@ def run_pipeline(args, rank, local_rank, world, dev):
 
     roofline = None
     if not args.no_roofline and rank == 0:
-        # kernel-level figures are taken with the stages strictly one after the other on the whole chip (no overlap, no CU
-        # partition): `roofline` describes the kernels, `value` the schedule
-        overlap = pipe.overlap_detector
-        pipe.overlap_detector = False
         ops.PROFILE = ops.ConvProfile()
         for _ in range(args.steps):
             pipe.run(images)
@@ -357,7 +351,6 @@ def run_pipeline(args, rank, local_rank, world, dev):
                           'tflops': round(gf / ms, 1) if ms > 0 else None,
                           'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None}
         roofline = conv_roofline(summ, stages)
-        pipe.overlap_detector = overlap
 
     peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
     if roofline is not None and peaks is not None:
@@ -401,7 +394,6 @@ def run_pipeline(args, rank, local_rank, world, dev):
                                f'-> MAC-VGG16 embed -> cosine NN match, gallery={args.gallery}x1024 (BASELINE configs[2]/[4] per-GPU shape)',
                    'images_per_gpu': ipg, 'global_images': world * ipg, 'proposals_per_image': proposals, 'gallery': args.gallery,
                    'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision,
-                   'stage_overlap': 'none' if args.no_overlap else 'detector of step i+1 queued on its own stream beside the embedder of step i',
                    'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
                    'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
                    'gallery_build_s': round(t_gallery, 3), 'collectives': cdist.backend_name()},

@@ -275,18 +275,10 @@ class BatchedPipeline:
     NHWC bf16 embedder input (no f32 crop tensor, no host round trip), one distance GEMM per batch.
     """
 
-    def __init__(self, detector, classifier, confidence_threshold=0.5, overlap_detector=True):
-        """overlap_detector: run the detector of a call on its own (high-priority) HIP stream, so that -- when the caller says
-        its images are ready (`run(..., inputs_ready=True)` or passes their ready event) -- the detector of call i + 1 is queued
-        BESIDE the embedder of call i instead of behind it.  Same kernels, same results; only the order in which the two stages'
-        launches reach the chip changes.  (Measured gain: 1.3 % -- the embedder's persistent kernels hold every CU, so the
-        detector only gets the tails of their launches; giving the detector its own XCD through CU-masked streams was measured
-        and rejected: profiles/r03_rejected_experiments.md.)"""
+    def __init__(self, detector, classifier, confidence_threshold=0.5):
         self.detector = detector
         self.classifier = classifier
         self.confidence_threshold = confidence_threshold
-        self.overlap_detector = overlap_detector
-        self._det_stream = None
 
     def _crops(self, images, det_out):
         """RoI crops of every image's confident boxes, launched WITHOUT knowing the counts on the host: the crop kernel reads
@@ -336,14 +328,12 @@ class BatchedPipeline:
                 'indices': indices.view(n, dpi, k), 'gaussians': gauss, 'embeddings': emb, 'counts_host': counts}
 
     @torch.no_grad()
-    def run(self, images, stage_events=None, inputs_ready=False):
+    def run(self, images, stage_events=None):
         """images: list of (3,H,W) f32 cuda tensors -> dict of device tensors:
         boxes (N,dpi,4), scores (N,dpi), count (N,) = #scores > confidence, indices (N,dpi,k) (-1 beyond count).
-        stage_events: optional list that receives (stage name, start event, end event) for detect / crop / embed / match (the
-        stages then run one after the other on the current stream: stage times are only meaningful without overlap).
-        inputs_ready: True = the images are fully materialised (nothing still being written by work queued on the current
-        stream), or a torch.cuda.Event after which they are; the detector then starts at once on its own stream, beside whatever
-        the current stream still holds (the previous call's embedder).  False (default): it waits for the current stream first."""
+        stage_events: optional list that receives (stage name, start event, end event) for detect / crop / embed / match.
+        (Queueing the detector of call i + 1 on its own stream beside the embedder of call i was measured: +1.3 % at best, and
+        the two stages' queues do not actually make progress side by side on this stack -- profiles/r03_rejected_experiments.md.)"""
         def mark():
             if stage_events is None:
                 return None
@@ -352,43 +342,20 @@ class BatchedPipeline:
             return e
 
         det = self.detector
-        n = len(images)
-        pin = self.__dict__.setdefault('_count_pins', {})
-        if n not in pin:
-            pin[n] = torch.empty(n, dtype=torch.int32).pin_memory()
-        main = torch.cuda.current_stream()
-        side = None
-        if self.overlap_detector and stage_events is None:
-            if self._det_stream is None:
-                self._det_stream = torch.cuda.Stream(device=det.engine().device, priority=-1)
-            side = self._det_stream
         t0 = mark()
+        det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
+        t1 = mark()
         # The one host synchronisation of a step -- the confidence-prefix counts, which size the embedder's batch -- is
         # taken BESIDE the crop kernels, not before them: the counts go to pinned host memory right behind the detector,
         # the crops (which read the counts on the device) are launched behind that copy, and the host wakes up as soon as
         # the copy has landed, i.e. while the crops still run, and queues the embedder's launches behind them.
-        if side is None:
-            det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
-            t1 = mark()
-            pin[n].copy_(det_out[4], non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record()
-        else:
-            if isinstance(inputs_ready, torch.cuda.Event):
-                side.wait_event(inputs_ready)
-            elif not inputs_ready:
-                ready = torch.cuda.Event()
-                ready.record(main)
-                side.wait_event(ready)
-            with torch.cuda.stream(side):
-                det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
-                pin[n].copy_(det_out[4], non_blocking=True)
-                copied = torch.cuda.Event()
-                copied.record(side)
-            for t in det_out:
-                t.record_stream(main)          # allocated on the detector stream, consumed on the embedder's
-            main.wait_event(copied)
-            t1 = None
+        n = len(images)
+        pin = self.__dict__.setdefault('_count_pins', {})
+        if n not in pin:
+            pin[n] = torch.empty(n, dtype=torch.int32).pin_memory()
+        pin[n].copy_(det_out[4], non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
         crops = self._crops(images, det_out)
         copied.synchronize()
         counts = pin[n].tolist()
