@@ -352,6 +352,14 @@ def run_pipeline(args, rank, local_rank, world, dev):
                           'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None}
         roofline = conv_roofline(summ, stages)
 
+    workloads = None
+    if not args.no_workloads and rank == 0:
+        # BASELINE configs[1] and configs[3] on this same box (a few hundred ms of GPU time): the driver only runs the default line
+        # (taken BEFORE the CPU-heavy legs: the oracle's OpenMP threads keep spinning for a while and slow the launch path)
+        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False)
+        workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
+                     'match_stress_configs3': match_stress_cases(dev, 200, 3)}
+
     peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
     if roofline is not None and peaks is not None:
         bare = peaks['bare_mfma_loop_tflops']
@@ -372,14 +380,6 @@ def run_pipeline(args, rank, local_rank, world, dev):
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
-    workloads = None
-    if not args.no_workloads and rank == 0:
-        # BASELINE configs[1] and configs[3] on this same box (a few hundred ms of GPU time): the driver only runs the default line
-        del pipe, out, outs
-        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False)
-        workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
-                     'match_stress_configs3': match_stress_cases(dev, 200, 3)}
-
     if rank != 0:
         return None
     total_images = world * ipg * args.steps
