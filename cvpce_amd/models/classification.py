@@ -32,6 +32,7 @@ MAX_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 256))  # crops per ke
 # 800 -> 157.6, 400 -> 153.5, 200 -> 150.6 images/s.
 FUSED_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 768))
 FUSED_EMBED_MAX = int(_os.environ.get('CVPCE_EMBED_MAX', 960))     # largest pass the 32-bit tensor limits allow with the fused stem (conv2_x output: 960 * 128 * 128 * 128 < 2^31)
+FUSED_EMBED_BATCH = min(FUSED_EMBED_BATCH, FUSED_EMBED_MAX)        # (an over-large CVPCE_EMBED_BATCH would hit the kernels' 32-bit guards instead of splitting the pass)
 
 
 def _passes(n, step, longest):

@@ -24,6 +24,8 @@ def wrap(name, fn, flops_fn, key_fn):
 oc = ops.conv2d
 ops.conv2d = wrap('conv', oc, lambda x, pc, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * pc.cout * 9 * pc.cin if pc.kh == 3 and pc.stride == 1 else 0.0,
                   lambda x, pc, **k: (tuple(x.shape[1:]), pc.cout, pc.kh, pc.stride, bool(k.get('pool'))))
+ops.conv2d_relu_mac = wrap('conv+mac', ops.conv2d_relu_mac, lambda x, pc, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * pc.cout * 9 * pc.cin,
+                           lambda x, pc, *a, **k: (tuple(x.shape[1:]), pc.cout, 3, 1, bool(k.get('pool'))))     # conv4_3 / conv5_3 with the fused MAC epilogue
 ops.vgg_stem = wrap('stem', ops.vgg_stem, lambda x, ps: ps.flops_per_pixel * x.shape[0] * x.shape[1] * x.shape[2], lambda x, ps: tuple(x.shape[1:]))
 ops.maxpool2d = wrap('maxpool', ops.maxpool2d, lambda x, *a, **k: 0.0, lambda x, *a, **k: tuple(x.shape[1:]))
 ops.global_max_into = wrap('global_max', ops.global_max_into, lambda x, *a: 0.0, lambda x, *a: tuple(x.shape[1:]))

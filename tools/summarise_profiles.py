@@ -22,8 +22,9 @@ for kind in ('fetch', 'write'):
     rows_ = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
     # only the launches of the LAST pipeline pass (= one timed step of bench.py: it starts with the 8 transform launches of the
     # step's images); the gallery build and the warm-up pass launch the same kernels on other batch sizes
-    marks = [int(r['Dispatch_Id']) for r in rows_ if 'gln_transform_kernel' in r['Kernel_Name']]
-    first = marks[-8] if len(marks) >= 8 else 0
+    # (round 3: the input transform of a step's 8 images is ONE launch of gln_transform_batch_kernel)
+    marks = [int(r['Dispatch_Id']) for r in rows_ if 'gln_transform_batch_kernel' in r['Kernel_Name']]
+    first = marks[-1] if marks else 0
     for r in rows_:
         if int(r['Dispatch_Id']) >= first:
             agg[r['Kernel_Name']].append(float(r['Counter_Value']))

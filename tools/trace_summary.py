@@ -3,8 +3,8 @@ GPU busy vs idle time inside that window (overlapping kernels on several streams
 import argparse, csv, glob, collections, sys
 ap = argparse.ArgumentParser()
 ap.add_argument('dir')
-ap.add_argument('--marker', default='gln_transform_kernel', help='kernel that starts a step (first launch of a detector pass)')
-ap.add_argument('--marker-per-step', type=int, default=4)
+ap.add_argument('--marker', default='gln_transform_batch_kernel', help='kernel that starts a step (first launch of a detector pass)')
+ap.add_argument('--marker-per-step', type=int, default=1)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--end-marker', default='nms_scan_kernel', help='kernel that ends the window of a step')
 a = ap.parse_args()

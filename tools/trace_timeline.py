@@ -1,9 +1,9 @@
 """dev tool: one step of a rocprofv3 --kernel-trace as a timeline (start offset, duration, gap since the latest end so far, kernel)."""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
-per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+per_step = 1   # one batched transform launch per detector pass (argv[2] kept for old command lines)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'gln_transform_kernel' in r['Kernel_Name']]
+marks = [i for i, r in enumerate(rows) if 'gln_transform_batch_kernel' in r['Kernel_Name']]
 s, e = marks[-2 * per_step], marks[-per_step]
 t0 = int(rows[s]['Start_Timestamp']); latest = t0
 for r in rows[s:e]:

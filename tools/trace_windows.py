@@ -7,7 +7,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
 kernel = sys.argv[2] if len(sys.argv) > 2 else 'void conv3x3_halo2_kernel'
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'gln_transform_kernel' in r['Kernel_Name']]
+marks = [i for i, r in enumerate(rows) if 'gln_transform_batch_kernel' in r['Kernel_Name']]
 bursts = []
 for m in marks:
     if not bursts or m - bursts[-1][-1] > 40:
