@@ -617,8 +617,10 @@ class GaussianLayerNetwork(nn.Module):
     """Drop-in for proposals.py:162-181 (eval mode): `model(list[Tensor(3,H,W)])` ->
     `list[dict(boxes, scores, labels, gaussians)]`, boxes in original pixels, scores descending."""
 
-    def __init__(self, resnet, num_classes, gaussian_loss_params={}, tanh=False, detections_per_img=1000, precision='bf16', **kwargs):
+    def __init__(self, resnet, num_classes, gaussian_loss_params={}, tanh=False, detections_per_img=1000, precision=None, **kwargs):
         super().__init__()
+        if precision is None:       # (the CLI commands keep the reference's options: the environment selects the mode there)
+            precision = os.environ.get('CVPCE_DETECTOR_PRECISION', 'bf16')
         if precision not in ops.STORAGE_TYPES:
             raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
         self.precision = precision
@@ -690,7 +692,8 @@ def gln_backbone(trainable_layers=5, pretrained=True):
 
 
 def gln(num_classes=1, trainable_layers=4, pretrained_backbone=True, tanh=False, gaussian_loss_params={},
-        detections_per_img=1000, precision='bf16'):
-    """proposals.py:202-203 (+ `precision`, keyword-only in spirit: 'bf16' | 'fp16' storage of the detector on the GPU)"""
+        detections_per_img=1000, precision=None):
+    """proposals.py:202-203 (+ `precision`, keyword-only in spirit: 'bf16' | 'fp16' storage of the detector on the GPU; None = the
+    CVPCE_DETECTOR_PRECISION environment variable, else 'bf16')"""
     return GaussianLayerNetwork(gln_backbone(trainable_layers, pretrained_backbone), num_classes, tanh=tanh,
                                 gaussian_loss_params=gaussian_loss_params, detections_per_img=detections_per_img, precision=precision)
