@@ -245,3 +245,24 @@ def test_precision_switch_repacks_and_restores(fp16_vs_oracle):
         assert torch.equal(x['boxes'], y['boxes']) and torch.equal(x['scores'], y['scores'])
     with pytest.raises(ValueError):
         det.set_precision('fp8')
+
+
+def test_fp16_detector_portrait_tanh_batch_of_mixed_sizes(cuda):
+    """The accuracy mode on what the square benchmark images do not exercise: a portrait image (800 x 1088 internal, ragged
+    tiles on every level), a second image of another size in the same padded batch, and the tanh Gaussian head."""
+    import accuracy
+    from cvpce_amd import synthetic
+    from oracle import gln as og
+    det = synthetic.synthetic_gln(seed=2, detections_per_img=100, tanh=True, precision='fp16')
+    sd = {k: v.clone() for k, v in det.state_dict().items()}
+    det = det.to(cuda)
+    products = synthetic.product_images(64, seed=201)
+    imgs = [synthetic.structured_shelf(11, 1360, 1000, products)[0], synthetic.structured_shelf(12, 700, 900, products)[0]]
+    hip = det([i.to(cuda) for i in imgs])
+    orc = og.gln_forward(imgs, sd, detections_per_img=100, tanh=True)
+    for h, o in zip(hip, orc):
+        assert h['gaussians'].shape == o['gaussians'].shape
+        d = h['gaussians'].cpu() - o['gaussians']                                   # tanh output in [-1, 1]
+        assert d.norm() / o['gaussians'].norm() < 0.01 and d.abs().max() < 0.1, (float(d.norm() / o['gaussians'].norm()), float(d.abs().max()))
+        pairs = accuracy.pair_boxes(h['boxes'].cpu(), o['boxes'])
+        assert len(pairs) >= 0.9 * len(o['boxes']), (len(pairs), len(o['boxes']))     # (100 boxes per image: one near-tie flip is a point)
