@@ -1,11 +1,13 @@
 // One ResNet bottleneck block in ONE launch:  out = relu( W3 . relu( conv3x3( relu(W1 . x + b1) ) + b2 ) + b3 + residual )
 // -- torchvision resnet50 `Bottleneck` (v1.5, stride 1) with FrozenBatchNorm2d folded into the weights, the block the
-// detector's body is made of (reached from cvpce/models/proposals.py:202-216 `resnet_fpn_backbone`; 11 of the 16 blocks of
-// ResNet-50 have stride 1: layer1 x3, layer2 x3, layer3 x5; layer4's 512-wide intermediates do not fit the LDS).
+// detector's body is made of (reached from cvpce/models/proposals.py:202-216 `resnet_fpn_backbone`).  Instantiated for
+// P = 64 / 128 / 256 (layer1 / layer2 / layer3; layer4's 512-wide intermediates do not fit the LDS) and verified for all
+// three; the detector USES it for layer1 only (cvpce_amd/ops.py FUSED_BOTTLENECK_MAX_PLANES): at P = 128 / 256 a tile is a
+// 107 / 317 us serial chain and a 100x100 / 50x50 map has too few tiles to hide it (profiles/r03_rejected_experiments.md).
 //
 // Why: as three launches the block moves its two P-channel intermediates through HBM (and pays three launch latencies on
 // the detector's critical chain: at 1-8 images per batch these launches are 15-100 us each and HBM- or latency-bound,
-// profiles/r03_detector_timeline.md).  Here a workgroup (8 waves) owns a 14x14-pixel output tile:
+// profiles/r03_detector_timeline.md; layer1 per 8-image block: 454 MB of HBM traffic instead of 656 MB, 190 vs 202 us).  Here a workgroup (8 waves) owns a 14x14-pixel output tile:
 //   stage A  mid1[16x16 halo pixels][P] = relu(W1 . x + b1), zero outside the image (it is the 3x3's zero padding);
 //            both MFMA operands straight from global memory in fragment layout (weights: L2 hits; x: the tile's pixels
 //            once), result as bf16/fp16 into LDS
