@@ -51,3 +51,18 @@ for name, pick_b in (('one XCD (bits = 7 mod 8)', {i for i in range(256) if i % 
     a, b = min(run2([0]) for _ in range(3)), min(run2([1]) for _ in range(3))
     both = min(run2([0, 1]) for _ in range(3))
     print(f'masked, B = {name}: 224 WGs on A {a:.2f} ms, 32 WGs on B {b:.2f} ms, together {both:.2f} ms', flush=True)
+
+# sequences of SHORT launches instead of one long launch per stream (the embedder is ~40 launches of 1-3 ms, the detector ~150 of 10-100 us)
+for na, ita, nb, itb in ((40, 8000, 40, 8000), (40, 8000, 600, 400), (40, 8000, 3000, 80)):
+    def seq(which):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for i in which:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(na if i == 0 else nb):
+                    T.probe_mfma_bf16(1, ita if i == 0 else itb, operands, sinks[i], 224 if i == 0 else 32)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) * 1e3
+    seq([0, 1])
+    a, b = min(seq([0]) for _ in range(2)), min(seq([1]) for _ in range(2))
+    both = min(seq([0, 1]) for _ in range(2))
+    print(f'masked sequences: A {na} x {ita} iters = {a:.2f} ms, B {nb} x {itb} iters = {b:.2f} ms, together {both:.2f} ms', flush=True)
