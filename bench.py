@@ -502,12 +502,15 @@ def match_stress_cases(dev, iters, warmup):
         graph.replay()
         torch.cuda.synchronize()
         reps = max(1, iters // per_graph)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            graph.replay()
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (reps * per_graph)
+        samples = []
+        for _ in range(3):                                   # median of three timed rounds: one slow replay must not decide a case
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                graph.replay()
+            e1.record(); torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1) * 1e3 / (reps * per_graph))
+        us = sorted(samples)[1]
         del graph
         flop = 2.0 * P * G * D
         byts = (G * D + P * D) * 2 + (G + P) * 4 + P * 8          # both operands once + norms + the (P,1) int64 result
