@@ -7,7 +7,7 @@
 //
 // Why: as three launches the block moves its two P-channel intermediates through HBM (and pays three launch latencies on
 // the detector's critical chain: at 1-8 images per batch these launches are 15-100 us each and HBM- or latency-bound,
-// profiles/r03_detector_timeline.md; layer1 per 8-image block: 454 MB of HBM traffic instead of 656 MB, 190 vs 202 us).  Here a workgroup (8 waves) owns a 14x14-pixel output tile:
+// profiles/r03_detector_timeline.md; layer1 per 8-image block: 454 MB of HBM traffic instead of 656 MB, 173 vs 202-206 us).  Here a workgroup (8 waves) owns a 14x14-pixel output tile:
 //   stage A  mid1[16x16 halo pixels][P] = relu(W1 . x + b1), zero outside the image (it is the 3x3's zero padding);
 //            both MFMA operands straight from global memory in fragment layout (weights: L2 hits; x: the tile's pixels
 //            once), result as bf16/fp16 into LDS
@@ -25,6 +25,9 @@ namespace {
 
 constexpr int BT = 14;            // output tile edge
 constexpr int BH = 16;            // halo tile edge (= pixels per MFMA column block)
+#ifndef BN_X_DEPTH
+#define BN_X_DEPTH(P) ((P) == 64 ? 4 : 2)   // ring slots of the x fragments in stage A (tools/dev A/B: -DBN_X_DEPTH(P)=2)
+#endif
 constexpr int BN_M1_PIX = 272;    // mid1 pixels in LDS: 16 x 16 + the wrap-around of the kw-shifted reads of the last row
 
 struct BneckArgs {
@@ -102,31 +105,38 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
             acc[b][1] = bias;
         }
         const int nk = a.Cin >> 5;                 // K-steps of 32
-        bf16x8 A[2][4], B[2][2];
-        // work items (K-step ks, sub-group sg) in order; the loads of item i+1 are issued before the MFMAs of item i
+        // x comes from HBM (2-3 us under load), the weights from L2: the x fragments run BD - 1 K-steps ahead of the MFMAs (at P = 64
+        // the accumulators are small and the registers are there), the weight fragments one work item ahead
+        constexpr int BD = BN_X_DEPTH(P);
+        bf16x8 A[2][4], B[BD][2];
+        // work items (K-step ks, sub-group sg) in order; the weight loads of item i+1 are issued before the MFMAs of item i
 #define BN_LOAD_A(SLOT, KS, SG)                                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
             A[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w1, woff[4 * (SG) + i_] + (unsigned)((KS) * 64), 0, 0));
 #define BN_LOAD_B(SLOT, KS)                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                       \
             B[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xin[i_] ? xoff[i_] + (unsigned)((KS) * 64) : 0xFFFFFFF0u, 0, 0));
-        BN_LOAD_B(0, 0)
+#pragma unroll
+        for (int h = 0; h < BD - 1; ++h)
+            if (h < nk) BN_LOAD_B(h, h)
         BN_LOAD_A(0, 0, 0)
-        for (int ks = 0; ks < nk; ks += 2) {
+        for (int ks = 0; ks < nk; ks += BD) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {             // two K-steps per trip: the B slot is a constant
-                const int k = ks + half;
-                if (k + 1 < nk) BN_LOAD_B((half ^ 1), k + 1)
+            for (int h = 0; h < BD; ++h) {                     // BD K-steps per trip: the B slot is a constant
+                const int k = ks + h;
+                if (k < nk) {
+                    if (k + BD - 1 < nk) BN_LOAD_B(((h + BD - 1) % BD), k + BD - 1)
 #pragma unroll
-                for (int sg = 0; sg < SG1; ++sg) {
-                    const int slot = (half * SG1 + sg) & 1;
-                    if (sg + 1 < SG1) { BN_LOAD_A((slot ^ 1), k, sg + 1) }
-                    else if (k + 1 < nk) { BN_LOAD_A((slot ^ 1), k + 1, 0) }
+                    for (int sg = 0; sg < SG1; ++sg) {
+                        const int slot = (h * SG1 + sg) & 1;
+                        if (sg + 1 < SG1) { BN_LOAD_A((slot ^ 1), k, sg + 1) }
+                        else if (k + 1 < nk) { BN_LOAD_A((slot ^ 1), k + 1, 0) }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[4 * sg + i][nt] = E::mfma16(A[slot][i], B[half][nt], acc[4 * sg + i][nt]);
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[4 * sg + i][nt] = E::mfma16(A[slot][i], B[h][nt], acc[4 * sg + i][nt]);
+                    }
                 }
             }
         }
