@@ -24,6 +24,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +34,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+MFMA_PEAK_CLOCK_MHZ = 2400.0           # the engine clock that peak is quoted at (same table)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -54,6 +56,7 @@ def parse():
     ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-clocks', action='store_true', help='skip the clock / power sampling leg (amdgpu hwmon, 3 s)')
     ap.add_argument('--no-peaks', action='store_true', help='skip the measured-peak microbenchmarks (library GEMM, device copy, bare MFMA loop)')
     ap.add_argument('--no-parity', action='store_true', help='skip the bounded HIP-vs-oracle accuracy sample')
     ap.add_argument('--no-h2d', action='store_true', help='skip the H2D-inclusive leg')
@@ -149,6 +152,62 @@ def measured_peaks(dev):
             'bare_mfma_loop_tflops': {'32x32x16': round(m32, 1), '16x16x32': round(m16, 1),
                                       'note': 'register operands, random data, one wave per SIMD, >= 2 s back to back (csrc/probe.hip)'},
             'nominal': {'mfma_bf16_dense_tflops': MFMA_BF16_DENSE_PEAK_TFLOPS, 'hbm_gbs': HBM_PEAK_GBS}}
+
+
+class ClockSampler:
+    """Shader clock and package power of the card while a leg runs, read from the amdgpu hwmon files (read-only sysfs; a host thread,
+    20 ms period).  MI355X runs this workload AT its power cap: the clock the MFMA peak is quoted at (2.4 GHz) is not the clock
+    the kernels get, and the median measured here prices `roofline.achieved` against the peak at the clock actually delivered."""
+
+    def __init__(self, dev, period=0.02):
+        self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
+        self.freq = self.power = None
+        import glob
+        pr = torch.cuda.get_device_properties(dev)         # the card of THIS process: a host has one drm node per partition
+        want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.'
+        for d in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+            if not os.path.basename(os.path.realpath(d)).startswith(want):
+                continue
+            for h in glob.glob(d + '/hwmon/hwmon*'):
+                if os.path.exists(h + '/freq1_input'):
+                    self.freq = h + '/freq1_input'                      # Hz
+                for nm in ('power1_input', 'power1_average'):
+                    if self.power is None and os.path.exists(h + '/' + nm):
+                        self.power = h + '/' + nm                       # microwatt
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            f, p = self._read(self.freq) if self.freq else None, self._read(self.power) if self.power else None
+            try:
+                self.samples.append((int(f) / 1e6 if f else None, int(p) / 1e6 if p else None))
+            except ValueError:
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self.samples, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+
+    def summary(self):
+        def med(xs):
+            xs = sorted(x for x in xs if x is not None)
+            return round(xs[len(xs) // 2], 1) if xs else None
+        return {'sclk_mhz_median': med([a for a, _ in self.samples]), 'power_w_median': med([b for _, b in self.samples]),
+                'samples': len(self.samples)}
 
 
 # algorithmic work per stage and image (SURVEY.md 8d): detector 298.4 GFLOP at 800x800, embed 40.09 GFLOP per crop,
@@ -351,6 +410,23 @@ def run_pipeline(args, rank, local_rank, world, dev):
                           'tflops': round(gf / ms, 1) if ms > 0 else None,
                           'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None}
         roofline = conv_roofline(summ, stages)
+        if not args.no_clocks:
+            # the clock and the power the card delivers while it runs this step (and, for comparison, its bare MFMA loop)
+            with ClockSampler(dev) as cs:
+                t_end = time.perf_counter() + 1.5
+                while time.perf_counter() < t_end:
+                    pipe.run(images)
+            clk = cs.summary()
+            with ClockSampler(dev) as cs:
+                ops.probe_mfma_bf16(1, seconds=1.5)
+            clk_bare = cs.summary()
+            if clk['sclk_mhz_median']:
+                at_clock = MFMA_BF16_DENSE_PEAK_TFLOPS * clk['sclk_mhz_median'] / MFMA_PEAK_CLOCK_MHZ
+                roofline['clocks'] = {'step': clk, 'bare_mfma_loop': clk_bare, 'peak_clock_mhz': MFMA_PEAK_CLOCK_MHZ,
+                                      'mfma_peak_at_step_clock_tflops': round(at_clock, 1),
+                                      'frac_at_step_clock': round(roofline['achieved'] / at_clock, 4),
+                                      'note': 'amdgpu hwmon freq1_input / power1 sampled every 20 ms over 1.5 s of steps; `frac` above stays '
+                                              'against the nominal 2.4 GHz peak'}
 
     workloads = None
     if not args.no_workloads and rank == 0:

@@ -22,8 +22,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 
 // compile-time timing experiments (never set in the shipped library; tools/ablate.sh): 1 no s_setprio around the MFMA
-// groups, 2 XCD-aware tile order, 4 no patch DMA in the loop, 8 no weight loads in the loop, 16 no output stores,
-// 32 no fragment reads in the loop, 64 no hand-off barrier (races: timing only), 256 (dispatch) 32-aligned maps to the wide kernel
+// groups, 2 XCD-aware tile order, 4 no patch DMA in the loop, 8 no weight loads in the loop, 16 no output stores (runtime-false predicate),
+// 32 no fragment reads in the loop, 64 no hand-off barrier (races: timing only), 256 (dispatch) 32-aligned maps to the wide kernel,
+// 512 in-kernel clock stamps (below; results unchanged)
 #ifndef CVPCE_DBG
 #define CVPCE_DBG 0
 #endif
@@ -57,6 +58,16 @@ struct Halo2Args {
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
 };
+
+#if CVPCE_DBG & 512
+// diagnostic build only (tools/ablate.sh conv3x3_halo2 512; tools/dev/kernel_clock.py): wave 0 of every workgroup stamps the shader-clock
+// counter (s_memtime) and the 100-MHz constant counter (s_memrealtime) around its whole K loop; their quotient is the clock the
+// kernel actually ran at (MI355X_MICROARCH.md, DVFS give-back item 6).  No output value depends on the stamps.
+__device__ unsigned long long cvpce_halo2_clock[1024][2];
+extern "C" int cvpce_debug_halo2_clock(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cvpce_halo2_clock), sizeof(cvpce_halo2_clock)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 template <typename E, bool POOL, bool GMAX>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
@@ -269,6 +280,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     G2_READ(0, 1)
 
     const int lp = lane & 15;
+#if CVPCE_DBG & 512
+    const unsigned long long ck0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int cc = 0; cc < total_chunks; ++cc) {
         // keep the per-step address variants inside the loop: hoisted they cost VGPRs the accumulators need
         asm volatile("" : "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]));
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                                 r[4 * mt + j] = fmaxf(v, fmaxf(up, dn));
                             }
                         }
-                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && !(CVPCE_DBG & 16)) {
+                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[0], r[1], r[2], r[3]}));
                         const uint2 h2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { r0[j] = relu_bits(r0[j]); r1[j] = relu_bits(r1[j]); }
                     }
-                    if (store_lane && co < a.Cout && !(CVPCE_DBG & 16)) {
+                    if (store_lane && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(r0)), h2 = __builtin_bit_cast(uint2, E::pack4(r1));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = keep ? u32x4{l2.x, l2.y, h2.x, h2.y} : u32x4{0u, 0u, 0u, 0u};
                     }
@@ -404,6 +418,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         sb_next = wbase(n_ct, (cchunk + 1 < nchunks) ? cchunk + 1 : 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the trailing prefetch
+#if CVPCE_DBG & 512
+    if (wc == 0 && lane == 0 && blockIdx.x < 1024) {
+        cvpce_halo2_clock[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - ck0_;
+        cvpce_halo2_clock[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - rt0_;
+    }
+#endif
 #undef G2_STEP
 #undef G2_HANDOFF
 #undef G2_ROWS_0_15

@@ -50,11 +50,18 @@ else:
         for _ in range(3):
             ops.conv2d(x, pc, act=1, pool=kind == 'conv_pool')
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            ops.conv2d(x, pc, act=1, pool=kind == 'conv_pool')
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        # groups of 10 launches back to back for REAL_LAYER_SECONDS (default: one group); the LAST group counts -- the card
+        # needs ~1 s under load to settle at the clock its power cap allows (a cold group reads 15-20 % low)
+        import time
+        t_end = time.perf_counter() + float(os.environ.get('REAL_LAYER_SECONDS', '0'))
+        while True:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.conv2d(x, pc, act=1, pool=kind == 'conv_pool')
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            if time.perf_counter() >= t_end:
+                break
         n, h, w, c = x.shape
         print(f'{nm} {ms:.3f} ms {2.0 * n * h * w * pc.cout * 9 * pc.cin / ms / 1e9:7.1f} TF', flush=True)
