@@ -27,6 +27,10 @@ def test_pipeline_line_small(cuda):
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert set(r['stages']) == {'detect', 'crop', 'embed', 'match'}
+    if 'clocks' in r:                                    # amdgpu hwmon readable on this box: the card's clock and power under the step
+        k = r['clocks']
+        assert 300 < k['step']['sclk_mhz_median'] <= k['peak_clock_mhz'] + 100 and k['step']['samples'] >= 10
+        assert abs(k['frac_at_step_clock'] - r['achieved'] / k['mfma_peak_at_step_clock_tflops']) < 1e-3
     assert d['value_with_h2d'] > 0 and d['upload_mb_per_step'] > 0
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
