@@ -3,7 +3,11 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows
   /root/reference/cvpce/models/proposals.py:51-139,162-203
 and, for everything inherited from torchvision 0.9 (not in the reference tree:
-"parity unpinned"), SURVEY.md Appendix A.
+"parity unpinned"), SURVEY.md Appendix A.  Of those inherited parts the ResNet-50
+body (`resnet_body`, `bottleneck`, `frozen_bn`) is pinned to an independent third
+implementation of the architecture -- transformers.ResNetModel, fixture
+tests/golden/resnet_body_hf.pt made by tests/golden/make_thirdparty.py; FPN, head,
+anchors, box coder, NMS and the transform have no vector to be checked against.
 
 `sd` is a reference-format state dict (keys `backbone.body.*`, `backbone.fpn.*`,
 `backbone.gaussian_layer.*`, `backbone.gaussian_subnet.*`, `head.*`).
