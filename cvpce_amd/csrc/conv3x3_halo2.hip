@@ -34,6 +34,11 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define G2_NPIX 324
 #define G2_A_BYTES (328 * 128)
 #define G2_NPIECE 41
+// masked launches (level atlas): the workgroup's own tile list and the tiles' pixel masks, built once in LDS
+#define G2_MAX_SEQ 512                                   // tiles per workgroup of a masked launch (checked on the host)
+#define G2_LTILE_OFF (3 * G2_A_BYTES)                    // [G2_MAX_SEQ] (ty << 16) | tx
+#define G2_LROW_OFF (G2_LTILE_OFF + G2_MAX_SEQ * 4)      // [G2_MAX_SEQ][16] one bit per pixel of a tile row
+#define G2_SMEM_MASKED (G2_LROW_OFF + G2_MAX_SEQ * 32)
 
 // Patch swizzle: 16-byte chunk c of patch pixel (py, px) lives at physical chunk
 // c ^ g2_swz(py, px).  ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...), i.e. a
@@ -89,6 +94,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     if (my_tiles <= 0) return;
     const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
 
+    // ---- masked launches: tile coordinates and per-row pixel masks of THIS workgroup's tiles go to LDS once.  Read from global
+    //      memory where they are used (a tile-map entry per tile change, a mask byte per stored row) every one of those loads
+    //      sits in the vmcnt queue behind the epilogue's stores and its wait drains them: 16 round trips per tile ----
+    unsigned* ltile = reinterpret_cast<unsigned*>(smem + G2_LTILE_OFF);
+    unsigned short* lrow = reinterpret_cast<unsigned short*>(smem + G2_LROW_OFF);
+    if (a.mask) {
+        for (int idx = tid; idx < my_tiles * 16; idx += 512) {
+            const int sq = idx >> 4, y = idx & 15;
+            const int r = ((lbid + sq * (int)gridDim.x) / a.ctiles) % a.tiles_per_image;
+            int ty, tx;
+            if (a.tile_map) {
+                const int packed = a.tile_map[r];
+                ty = packed >> 16;
+                tx = packed & 0xFFFF;
+            } else {
+                ty = r / a.tiles_x;
+                tx = r - ty * a.tiles_x;
+            }
+            const int oy = ty * G2_T + y;
+            unsigned bits = 0;
+            if (oy < a.H) {
+#pragma unroll
+                for (int c = 0; c < G2_T; ++c) {
+                    const int ox = tx * G2_T + c;
+                    if (ox < a.W && a.mask[oy * a.W + ox]) bits |= 1u << c;
+                }
+            }
+            lrow[idx] = (unsigned short)bits;
+            if (y == 0) ltile[sq] = (unsigned)((ty << 16) | tx);
+        }
+        __syncthreads();
+    }
+
     // tile seq -> (image, tile row, tile column, cout tile); cout tile fastest
     auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct) {
         const int t = lbid + seq * (int)gridDim.x;
@@ -96,8 +134,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         const int p = t / a.ctiles;
         n = p / a.tiles_per_image;
         const int r = p - n * a.tiles_per_image;
-        if (a.tile_map) {
-            const int packed = a.tile_map[r];
+        if (a.mask) {
+            const int packed = __builtin_amdgcn_readfirstlane((int)ltile[seq]);
             ty = packed >> 16;
             tx = packed & 0xFFFF;
         } else {
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                     const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
                     const bool store_lane = oy < a.H && ox < a.W;     // ragged right / bottom tiles
                     bool keep = true;                // masked-out pixels (gaps of a level atlas) are stored as zeros
-                    if (a.mask && store_lane) keep = a.mask[oy * a.W + ox] != 0;
+                    if (a.mask) keep = ((lrow[seq * 16 + nt] >> col) & 1u) != 0;
                     f32x4 r0 = acc[0][nt], r1 = acc[1][nt];
                     if (a.relu) {
 #pragma unroll
@@ -438,14 +476,15 @@ template <typename E, bool POOL, bool GMAX>
 static int launch_halo2(Halo2Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 255) / 256;
     a.ntiles = a.ptiles * a.ctiles;
-    const int smem = 3 * G2_A_BYTES;
+    const int smem = a.mask ? G2_SMEM_MASKED : 3 * G2_A_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<E, POOL, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<E, POOL, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_MASKED) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
+    if (a.mask && (a.ntiles + grid - 1) / grid > G2_MAX_SEQ) return CVPCE_ERR_ARG;   // the workgroup's tile list lives in LDS
     hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }

@@ -96,7 +96,8 @@ int cvpce_conv3x3_halo_mac(const void* in, const void* wgt, const float* bias, v
  * Outputs on mask-0 pixels are stored as zeros, so the result is again a valid atlas (the gaps ARE the next layer's
  * zero padding) and one launch replaces one launch per level.  tile_map (optional, device): the n_tiles 16x16-pixel tiles
  * to compute, (ty << 16) | tx, the same list for every image -- tiles that lie wholly in a gap are left out and `out` must
- * then already hold zeros there (the caller keeps zero-initialised atlas buffers). */
+ * then already hold zeros there (the caller keeps zero-initialised atlas buffers).  At most 512 x (workgroups of the persistent
+ * grid) tiles per launch: every workgroup keeps its own tiles' coordinates and pixel masks in LDS. */
 int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
                               const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
                               int Cout_pad, int relu, void* stream);
