@@ -523,23 +523,31 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool):
         assert rel_err(nchw(y), ref) < 1e-2
 
 
-def test_conv3x3_atlas_masked(cuda):
+@pytest.mark.parametrize('n,use_map', [(3, False), (3, True), (90, True), (50, False)])
+def test_conv3x3_atlas_masked(cuda, n, use_map):
     """cvpce_conv3x3_halo_masked: two maps packed side by side with a one-pixel zero gap == the conv applied to each map
-    separately; gap pixels of the output are exactly zero (so the output is again a valid atlas)."""
+    separately; gap pixels of the output are exactly zero (so the output is again a valid atlas).  With 90 / 50 images every
+    persistent workgroup walks several tiles (its tile list and their pixel masks live in LDS), with and without a tile map."""
     from cvpce_amd import ops
     g = torch.Generator().manual_seed(5)
-    a = torch.randn(3, 21, 30, 128, generator=g).to(BF)
-    b = torch.randn(3, 9, 14, 128, generator=g).to(BF)
+    a = torch.randn(n, 21, 30, 128, generator=g).to(BF)
+    b = torch.randn(n, 9, 14, 128, generator=g).to(BF)
     wgt = torch.randn(256, 128, 3, 3, generator=g) / math.sqrt(9 * 128)
     bias = torch.randn(256, generator=g) * 0.1
     pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda)
-    atlas = torch.zeros(3, 21, 45, 128, dtype=BF)
+    atlas = torch.zeros(n, 21, 61, 128, dtype=BF)      # columns 45..60: a tile column that lies wholly in the gap
     atlas[:, :, :30] = a
     atlas[:, 5:14, 31:45] = b
-    mask = torch.zeros(21, 45, dtype=torch.uint8)
+    mask = torch.zeros(21, 61, dtype=torch.uint8)
     mask[:, :30] = 1
     mask[5:14, 31:45] = 1
-    y = ops.conv3x3_atlas(atlas.to(cuda), pc, mask.to(cuda), act=1)
+    if use_map:
+        tile_map = ops.atlas_tile_map(mask.to(cuda))
+        assert tile_map.numel() == 5                                   # of 2 x 4 tiles: the last column and (1, 2) are all gap
+        out = torch.zeros(n, 21, 61, 256, dtype=BF, device=cuda)
+        y = ops.conv3x3_atlas(atlas.to(cuda), pc, mask.to(cuda), act=1, tile_map=tile_map, out=out)
+    else:
+        y = ops.conv3x3_atlas(atlas.to(cuda), pc, mask.to(cuda), act=1)
     ops.HALO_RAGGED = True
     try:
         ya = ops.conv2d(a.to(cuda), pc, act=1)
