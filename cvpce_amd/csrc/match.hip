@@ -9,7 +9,7 @@
 // Layout: Q [Qn][D], G [Gn][D] row-major (K contiguous for both operands),
 // bf16 storage, fp32 accumulate (v_mfma_f32_32x32x16_bf16); or fp32 storage
 // on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32) for index-exact parity.
-// Tile 128 gallery rows x 128 queries, K-step 64, swizzled LDS, register
+// Tile 128 gallery rows x 128 | 64 queries (chosen per launch by whole rounds of the chip), K-step 64, swizzled LDS, register
 // staged double buffer (same pipeline as conv_igemm).  Epilogue: the tile's
 // distances go to LDS as [g][q] (conflict-free both ways), every query finds
 // its k smallest (distance, index) pairs lexicographically (ties -> lowest
@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 #include <math.h>
+#include <cstdlib>
 #include <type_traits>
 
 #define MT_TG 128
@@ -68,14 +69,20 @@ extern "C" int cvpce_row_norms(const void* x, float* out, int rows, int D, int i
 // lexicographic (d, i) < (e, j)
 __device__ __forceinline__ bool lex_lt(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
 
-template <bool F32>
-__global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
+// TQ = queries per tile: 128 (waves 2 x 2, 64 gallery rows x 64 queries each) or 64 (64 x 32 each; 48 KiB of LDS, three
+// workgroups per CU).  Which one a launch takes is a question of tile COUNT, not of kernel quality: 1 600 x 10 000 gives
+// 13 x 79 = 1 027 tiles of 128 x 128 -- on 512 workgroup slots a third round for three tiles.
+template <bool F32, int TQ>
+__global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs a) {
+    static_assert(TQ == 128 || TQ == 64, "query tile");
+    constexpr int NT = TQ / 64;                      // 32-query MFMA blocks per wave
     // element size 2 (bf16) or 4 (f32); one LDS row = MT_BK elements
     constexpr int ES = F32 ? 4 : 2;
     constexpr int ROWB = MT_BK * ES;                 // bytes per tile row: 128 / 256
     constexpr int CPR = ROWB / 16;                   // 16-B chunks per row: 8 / 16
     constexpr int RPP = 256 / CPR;                   // 32 / 16
     constexpr int PASS = MT_TG / RPP;                // 4 / 8
+    constexpr int PASSQ = TQ / RPP;                  // query rows per thread
     constexpr int RPB = (256 / ROWB) > 0 ? (256 / ROWB) : 1;   // rows per 256-B bank row: 2 / 1
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Gs = smem;                                  // [2][128 rows][ROWB]
@@ -96,16 +103,18 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
     // whole iteration (and the barrier) to land before it is written to LDS -- one step deep, every iteration waited out most
     // of an L2 / HBM round trip (~2 us per K-step, the whole kernel was that latency times D / 64)
     constexpr int NS = F32 ? 1 : 2;      // staging depth (the f32 rows are twice as wide: two sets would spill)
-    u32x4 greg[NS][PASS], qreg[NS][PASS];
+    u32x4 greg[NS][PASS], qreg[NS][PASSQ];
     auto load_tile = [&](int kt, int slot) {
 #pragma unroll
         for (int i = 0; i < PASS; ++i) {
             int gr = tile_g * MT_TG + r0 + i * RPP;
-            int qr = tile_q * MT_TQ + r0 + i * RPP;
             // buffer loads: rows past the end are out of the descriptor's range and read as zeros -- no branch around the load,
             // so the compiler can count the loads in flight (behind a branch it waits with vmcnt(0): the staging collapses)
             greg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, (unsigned)gr * (unsigned)rowbytes + (unsigned)(kt * ROWB + c * 16), 0, 0);
-            qreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_q, (unsigned)qr * (unsigned)rowbytes + (unsigned)(kt * ROWB + c * 16), 0, 0);
+            if (i < PASSQ) {
+                int qr = tile_q * TQ + r0 + i * RPP;
+                qreg[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_q, (unsigned)qr * (unsigned)rowbytes + (unsigned)(kt * ROWB + c * 16), 0, 0);
+            }
         }
     };
     auto store_tile = [&](int buf, int slot) {
@@ -114,15 +123,15 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
             int row = r0 + i * RPP;
             int phys = c ^ ((row / RPB) & (CPR - 1));
             *reinterpret_cast<u32x4*>(Gs + (size_t)buf * MT_TG * ROWB + row * ROWB + phys * 16) = greg[slot][i];
-            *reinterpret_cast<u32x4*>(Qs + (size_t)buf * MT_TQ * ROWB + row * ROWB + phys * 16) = qreg[slot][i];
+            if (i < PASSQ) *reinterpret_cast<u32x4*>(Qs + (size_t)buf * TQ * ROWB + row * ROWB + phys * 16) = qreg[slot][i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -144,23 +153,26 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
         else load_tile(kt + 1 < nk ? kt + 1 : last, 0);
         __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the MFMA section (the scheduler otherwise sinks them to the barrier)
         const unsigned char* Gb = Gs + (size_t)cur * MT_TG * ROWB;
-        const unsigned char* Qb = Qs + (size_t)cur * MT_TQ * ROWB;
+        const unsigned char* Qb = Qs + (size_t)cur * TQ * ROWB;
         if constexpr (!F32) {
 #pragma unroll
             for (int kk = 0; kk < MT_BK / 16; ++kk) {
                 const int chunk = kk * 2 + lh;
-                bf16x8 af[2], bfr[2];
+                bf16x8 af[2], bfr[NT];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     int row = wc * 64 + mt * 32 + lr;
                     af[mt] = *reinterpret_cast<const bf16x8*>(Gb + row * ROWB + ((chunk ^ ((row / RPB) & (CPR - 1))) * 16));
-                    int rowq = wp * 64 + mt * 32 + lr;
-                    bfr[mt] = *reinterpret_cast<const bf16x8*>(Qb + rowq * ROWB + ((chunk ^ ((rowq / RPB) & (CPR - 1))) * 16));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int rowq = wp * 32 * NT + nt * 32 + lr;
+                    bfr[nt] = *reinterpret_cast<const bf16x8*>(Qb + rowq * ROWB + ((chunk ^ ((rowq / RPB) & (CPR - 1))) * 16));
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
             }
         } else {
@@ -170,20 +182,23 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
                 // lane half lh reads the 16-B chunk (2*k4 + lh): k = 8*k4 + 4*lh + {0..3}; the 4 MFMAs then pair
                 // element e of half 0 with element e of half 1 -- a permutation of k, identical for A and B.
                 const int chunk = k4 * 2 + lh;
-                f32x4 af[2], bfr[2];
+                f32x4 af[2], bfr[NT];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     int row = wc * 64 + mt * 32 + lr;
                     af[mt] = *reinterpret_cast<const f32x4*>(Gb + row * ROWB + ((chunk ^ ((row / RPB) & (CPR - 1))) * 16));
-                    int rowq = wp * 64 + mt * 32 + lr;
-                    bfr[mt] = *reinterpret_cast<const f32x4*>(Qb + rowq * ROWB + ((chunk ^ ((rowq / RPB) & (CPR - 1))) * 16));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int rowq = wp * 32 * NT + nt * 32 + lr;
+                    bfr[nt] = *reinterpret_cast<const f32x4*>(Qb + rowq * ROWB + ((chunk ^ ((rowq / RPB) & (CPR - 1))) * 16));
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][e], bfr[nt][e], acc[mt][nt], 0, 0, 0);
             }
         }
@@ -199,19 +214,20 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
     if (kt < nk) k_step(kt, std::integral_constant<int, 1>{});     // odd number of K-steps
 
     // ---- epilogue: distances -> LDS [g][q], then per-query top-k -------------
-    float* Tl = reinterpret_cast<float*>(smem);                       // 128 x 128 f32 = 64 KiB
-    float* cd = reinterpret_cast<float*>(smem + MT_TG * MT_TQ * 4);   // [2][128]
-    int* cix = reinterpret_cast<int*>(smem + MT_TG * MT_TQ * 4 + 2 * 128 * 4);
-    float* s_gn = reinterpret_cast<float*>(smem + MT_TG * MT_TQ * 4 + 4 * 128 * 4);   // the tile's 128 gallery norms (one coalesced load
+    constexpr int NH = 256 / TQ;                                      // threads per query in the scan: 2 | 4 parts of the 128 gallery rows
+    float* Tl = reinterpret_cast<float*>(smem);                       // 128 x TQ f32 = 64 | 32 KiB
+    float* cd = reinterpret_cast<float*>(smem + MT_TG * TQ * 4);      // [NH][TQ]
+    int* cix = reinterpret_cast<int*>(smem + MT_TG * TQ * 4 + 256 * 4);
+    float* s_gn = reinterpret_cast<float*>(smem + MT_TG * TQ * 4 + 2 * 256 * 4);      // the tile's 128 gallery norms (one coalesced load
     if (tid < MT_TG) {                                                                 // instead of 64 scattered ones per lane)
         const int gg = tile_g * MT_TG + tid;
         s_gn[tid] = (gg < a.Gn) ? a.gn[gg] : 1.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int ql = wp * 64 + nt * 32 + lr;
-        const int qg = tile_q * MT_TQ + ql;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ql = wp * 32 * NT + nt * 32 + lr;
+        const int qg = tile_q * TQ + ql;
         const float qn = (qg < a.Qn) ? a.qn[qg] : 1.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -224,35 +240,38 @@ __global__ __launch_bounds__(256, 2) void match_kernel(MatchArgs a) {
                     d = 1.f - acc[mt][nt][r] / (qn * s_gn[gl]);
                     if (!(d == d)) d = INFINITY;   // a NaN distance (non-finite embedding) sorts last and still yields a valid index
                 }
-                Tl[gl * MT_TQ + ql] = d;
+                Tl[gl * TQ + ql] = d;
             }
     }
     __syncthreads();
-    const int ql = tid & 127, half = tid >> 7;
-    const int qg = tile_q * MT_TQ + ql;
+    const int ql = tid & (TQ - 1), part = tid / TQ;
+    const int qg = tile_q * TQ + ql;
     float pd = -INFINITY;
     int pi = -1;
     for (int r = 0; r < a.k; ++r) {
         float bd = INFINITY;
         int bi = 0x7FFFFFFF;
-        for (int g0 = half * 64; g0 < half * 64 + 64; g0 += 8) {
+        for (int g0 = part * (MT_TG / NH); g0 < (part + 1) * (MT_TG / NH); g0 += 8) {
             float dv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dv[u] = Tl[(g0 + u) * MT_TQ + ql];          // 8 LDS reads in flight
+            for (int u = 0; u < 8; ++u) dv[u] = Tl[(g0 + u) * TQ + ql];             // 8 LDS reads in flight
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int gi = tile_g * MT_TG + g0 + u;
                 if (lex_lt(pd, pi, dv[u], gi) && lex_lt(dv[u], gi, bd, bi)) { bd = dv[u]; bi = gi; }
             }
         }
-        cd[half * 128 + ql] = bd;
-        cix[half * 128 + ql] = bi;
+        cd[part * TQ + ql] = bd;
+        cix[part * TQ + ql] = bi;
         __syncthreads();
-        const float od = cd[(half ^ 1) * 128 + ql];
-        const int oi = cix[(half ^ 1) * 128 + ql];
-        if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+#pragma unroll
+        for (int p = 1; p < NH; ++p) {                   // every part learns the tile's minimum: it bounds its next round
+            const float od = cd[((part + p) & (NH - 1)) * TQ + ql];
+            const int oi = cix[((part + p) & (NH - 1)) * TQ + ql];
+            if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+        }
         pd = bd; pi = bi;
-        if (half == 0 && qg < a.Qn) {
+        if (part == 0 && qg < a.Qn) {
             const size_t o = ((size_t)qg * a.tiles_g + tile_g) * a.k + r;
             a.part_d[o] = bd;
             a.part_i[o] = bi;
@@ -325,25 +344,40 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
     MatchArgs a;
     a.q = queries; a.g = gallery; a.qn = q_norms; a.gn = g_norms; a.Qn = Qn; a.Gn = Gn; a.D = D; a.k = k;
     a.tiles_g = (Gn + MT_TG - 1) / MT_TG;
-    a.tiles_q = (Qn + MT_TQ - 1) / MT_TQ;
+    // query tile of the bf16 kernel: 64-query tiles cost ~0.6 of a 128-query tile and run three to a CU instead of two; the
+    // cheaper schedule in whole rounds of the chip wins (CVPCE_MATCH_TQ = 64 | 128 forces one: dev A/B)
+    int tq = MT_TQ;
+    if (!is_f32) {
+        static const int forced = []() { const char* e = getenv("CVPCE_MATCH_TQ"); return e ? atoi(e) : 0; }();
+        const long long cus = g_cvpce_persistent_wgs;
+        const long long t128 = (long long)a.tiles_g * ((Qn + 127) / 128), t64 = (long long)a.tiles_g * ((Qn + 63) / 64);
+        const double c128 = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 1.0, c64 = (double)((t64 + 3 * cus - 1) / (3 * cus)) * 0.6;
+        tq = forced == 64 || forced == 128 ? forced : (c64 < c128 ? 64 : 128);
+    }
+    a.tiles_q = (Qn + tq - 1) / tq;
     a.part_d = (float*)workspace;
     a.part_i = (int*)((char*)workspace + ((size_t)Qn * a.tiles_g * k * 4 + 255) / 256 * 256);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(a.tiles_g * a.tiles_q);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)match_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 256) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)match_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 256) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)match_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4 + 2048 + 512) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)match_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4 + 2048 + 512) != hipSuccess)
+            return CVPCE_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)match_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128) != hipSuccess)
             return CVPCE_ERR_LAUNCH;
         attr_set = true;
     }
     if (is_f32) {
         size_t smem = (size_t)2 * 2 * 128 * 256;    // 128 KiB staging (>= 66 KiB epilogue image)
-        hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), smem, s, a);
-    } else {
+        hipLaunchKernelGGL((match_kernel<true, 128>), grid, dim3(256), smem, s, a);
+    } else if (tq == 128) {
         size_t smem = (size_t)128 * 128 * 4 + 2048 + 512;  // epilogue image (+ candidates, + the tile's gallery norms) dominates (staging needs 64 KiB)
-        hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), smem, s, a);
+        hipLaunchKernelGGL((match_kernel<false, 128>), grid, dim3(256), smem, s, a);
+    } else {
+        size_t smem = (size_t)2 * (128 + 64) * 128;        // 48 KiB of staging dominates (epilogue image 32 KiB + 2.5 KiB)
+        hipLaunchKernelGGL((match_kernel<false, 64>), grid, dim3(256), smem, s, a);
     }
     hipLaunchKernelGGL(match_merge_kernel, dim3((Qn + 3) / 4), dim3(256), 0, s, a.part_d, a.part_i, Qn, a.tiles_g * k,
                        k, out_idx, out_dist);
