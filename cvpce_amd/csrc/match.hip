@@ -90,7 +90,24 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wc = wid >> 1, wp = wid & 1;
-    const int tile_g = blockIdx.x % a.tiles_g, tile_q = blockIdx.x / a.tiles_g;
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin, each with its own 4-MiB L2; with gallery tiles
+    // fastest over blockIdx every XCD touches EVERY gallery tile (20 MB at 10 000 x 1 024) and the operands stream from beyond L2
+    // (9.5 TB/s measured at 1 600 queries: 43 FLOP per byte of a 128 x 64 tile = the 400 TFLOP/s the kernel was stuck at).
+    // Here XCD x gets a contiguous range of the logical order (xcd_remap), and that order is gallery-class major: class c =
+    // the gallery tiles c, c + 8, ... with all their query tiles -- an eighth of the gallery (2.5 MB) stays resident in the
+    // XCD's L2 while the query tiles sweep past it.
+    int tile_g, tile_q;
+    {
+        int l = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        int cls = 0, ng = (a.tiles_g + 7) >> 3;
+        while (cls < 7 && l >= ng * a.tiles_q) {       // at most 7 steps, scalar
+            l -= ng * a.tiles_q;
+            ++cls;
+            ng = (a.tiles_g - cls + 7) >> 3;
+        }
+        tile_q = l / ng;
+        tile_g = cls + 8 * (l - tile_q * ng);
+    }
     const int c = tid % CPR, r0 = tid / CPR;
 
     const unsigned char* gbase = (const unsigned char*)a.g;
@@ -102,7 +119,8 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
     // register staging, TWO K-steps deep: the loads of step kt + 2 are issued before the MFMAs of step kt, so a load has a
     // whole iteration (and the barrier) to land before it is written to LDS -- one step deep, every iteration waited out most
     // of an L2 / HBM round trip (~2 us per K-step, the whole kernel was that latency times D / 64)
-    constexpr int NS = F32 ? 1 : 2;      // staging depth (the f32 rows are twice as wide: two sets would spill)
+    constexpr int NS = F32 ? 1 : 2;      // staging slots = K-steps a load has to land (the f32 rows are twice as wide: two sets would spill;
+                                         // three slots measured the same as two: 67-69 vs 66 us at 1 600 x 10 000 x 1 024)
     u32x4 greg[NS][PASS], qreg[NS][PASSQ];
     auto load_tile = [&](int kt, int slot) {
 #pragma unroll
@@ -137,20 +155,19 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
 
     const int nk = a.D / MT_BK;
     const int lr = lane & 31, lh = lane >> 5;
-    load_tile(0, 0);
-    if (NS == 2) load_tile(nk > 1 ? 1 : 0, 1);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) load_tile(sl < nk ? sl : nk - 1, sl);
     store_tile(0, 0);
     __syncthreads();
     int cur = 0;
-    // (the loop is unrolled by two so that the staging slot of a step is a compile-time index: registers, not scratch)
+    // (the loop is unrolled by NS so that the staging slot of a step is a compile-time index: registers, not scratch)
     auto k_step = [&](int kt, auto slot_c) {
-        constexpr int SLOT = decltype(slot_c)::value % NS;  // slot holding step kt + 1; the loads of step kt + 2 go to the other one
+        constexpr int SLOT = decltype(slot_c)::value % NS;  // slot holding step kt + 1; the loads of step kt + NS go to the slot step kt came from
         // No branch around the loads or the LDS stores (past the last K-step they re-fetch the last tile into buffers nobody
         // reads): with one straight-line path the compiler's vmcnt bookkeeping is exact -- behind `if (kt + 2 < nk)` it waited
         // for the minimum over both paths, i.e. for the newest loads as well.
         const int last = nk - 1;
-        if (NS == 2) load_tile(kt + 2 < nk ? kt + 2 : last, (SLOT + 1) % NS);
-        else load_tile(kt + 1 < nk ? kt + 1 : last, 0);
+        load_tile(kt + NS < nk ? kt + NS : last, (SLOT + NS - 1) % NS);
         __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the MFMA section (the scheduler otherwise sinks them to the barrier)
         const unsigned char* Gb = Gs + (size_t)cur * MT_TG * ROWB;
         const unsigned char* Qb = Qs + (size_t)cur * TQ * ROWB;
@@ -203,15 +220,24 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
             }
         }
         store_tile(cur ^ 1, SLOT);
-        __syncthreads();
+        // raw barrier: `__syncthreads()` also waits for vmcnt(0), i.e. for the loads of step kt + 2 issued a moment ago -- every
+        // K-step then costs a whole L2 / HBM round trip and the two-deep staging hides nothing.  What the hand-off needs is that
+        // this wave's LDS stores have landed (lgkmcnt) and that every wave is past its reads of the other buffer (the barrier).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         cur ^= 1;
     };
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        k_step(kt, std::integral_constant<int, 1>{});
-        k_step(kt + 1, std::integral_constant<int, 0>{});
+    for (; kt + NS <= nk; kt += NS) {
+        k_step(kt, std::integral_constant<int, 1 % NS>{});
+        if constexpr (NS > 1) k_step(kt + 1, std::integral_constant<int, 2 % NS>{});
+        if constexpr (NS > 2) k_step(kt + 2, std::integral_constant<int, 3 % NS>{});
     }
-    if (kt < nk) k_step(kt, std::integral_constant<int, 1>{});     // odd number of K-steps
+    if constexpr (NS > 1) {                                         // the K-steps left over
+        if (kt < nk) k_step(kt, std::integral_constant<int, 1 % NS>{});
+        if constexpr (NS > 2) { if (kt + 1 < nk) k_step(kt + 1, std::integral_constant<int, 2 % NS>{}); }
+    }
 
     // ---- epilogue: distances -> LDS [g][q], then per-query top-k -------------
     constexpr int NH = 256 / TQ;                                      // threads per query in the scan: 2 | 4 parts of the 128 gallery rows
