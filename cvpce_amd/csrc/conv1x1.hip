@@ -26,7 +26,10 @@ template <typename E>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = (int)blockIdx.x * 4 + wid;
+    // workgroups are dealt to the 8 XCDs round-robin: with the remap the (up to 8) workgroups that share a pixel tile -- one per
+    // four cout tiles, cout fastest -- run on ONE XCD and its L2 serves their re-reads; in blockIdx order a 2048-cout layer
+    // fetched every input row eight times from beyond L2
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wid;
     if (tile >= a.ntiles) return;
     const int ct = tile % a.ntile_n, pt = tile / a.ntile_n;
     const int l16 = lane & 15, lq = lane >> 4;
