@@ -303,11 +303,7 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
 template <typename E, int P>
 int launch_bneck(const BneckArgs& a, hipStream_t stream) {
     const int smem = BN_M1_PIX * 2 * P;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)bneck_kernel<E, P>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!cvpce_smem_attr_done<bneck_kernel<E, P>>((const void*)bneck_kernel<E, P>, smem)) return CVPCE_ERR_LAUNCH;
     hipLaunchKernelGGL((bneck_kernel<E, P>), dim3((unsigned)(a.N * a.tiles_x * a.tiles_y)), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -100,6 +101,21 @@ __device__ __forceinline__ float quad_max_nonneg(float x) {
 // number of workgroups the persistent kernels launch at most (= the CUs their stream may use: 256, or fewer under a CU mask);
 // set by cvpce_set_persistent_workgroups (elementwise.hip)
 extern int g_cvpce_persistent_wgs;
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instance, device): the attribute belongs to the device that
+// is current when it is set, so a process that drives a second GPU must set it there too; the flag is an atomic bit per device
+// (two host threads may race to set it -- setting it twice is harmless).
+template <auto Kernel>
+static inline bool cvpce_smem_attr_done(const void* fn, int bytes) {
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 
 static inline int cvpce_check_launch() {
     hipError_t e = hipGetLastError();

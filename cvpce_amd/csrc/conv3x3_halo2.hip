@@ -39,6 +39,10 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define G2_LTILE_OFF (3 * G2_A_BYTES)                    // [G2_MAX_SEQ] (ty << 16) | tx
 #define G2_LROW_OFF (G2_LTILE_OFF + G2_MAX_SEQ * 4)      // [G2_MAX_SEQ][16] one bit per pixel of a tile row
 #define G2_SMEM_MASKED (G2_LROW_OFF + G2_MAX_SEQ * 32)
+// work-list launches (the embedder's constant-padding tile skipping, skiplist.hip): the first G2_MAX_SEQ entries of the
+// workgroup's own list in LDS (later ones, if any, are read from global memory where they are needed)
+#define G2_LLIST_OFF (3 * G2_A_BYTES)                    // [G2_MAX_SEQ] 8-byte entries
+#define G2_SMEM_LIST (G2_LLIST_OFF + G2_MAX_SEQ * 8)
 
 // Patch swizzle: 16-byte chunk c of patch pixel (py, px) lives at physical chunk
 // c ^ g2_swz(py, px).  ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...), i.e. a
@@ -62,6 +66,10 @@ struct Halo2Args {
     int N, H, W, Cin, Cout, K_pad, relu;
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
+    // LIST launches: the tiles to compute, ((ey_in << 16 | ex_in) << 32) | (n << 16) | (ty << 8) | tx, crop-major; *list_count
+    // entries (device-resident); input pixels with y >= ey_in or x >= ex_in are read from image N - 1 (the constant crop)
+    const unsigned long long* list;
+    const int* list_count;
 };
 
 #if CVPCE_DBG & 512
@@ -74,7 +82,7 @@ extern "C" int cvpce_debug_halo2_clock(unsigned long long* host_out) {
 }
 #endif
 
-template <typename E, bool POOL, bool GMAX>
+template <typename E, bool POOL, bool GMAX, bool LIST>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     constexpr int TC = 256, NB = 16;
 
@@ -90,9 +98,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 
     const int nchunks = a.Cin >> 6;
     const int lbid = (CVPCE_DBG & 2) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    const int my_tiles = (a.ntiles - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    int ntiles_ = a.ntiles;
+    if constexpr (LIST) ntiles_ = __builtin_amdgcn_readfirstlane(*a.list_count) * a.ctiles;     // <= a.ntiles (checked by the list builder)
+    const int my_tiles = (ntiles_ - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
     if (my_tiles <= 0) return;
     const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
+    unsigned long long* llist = reinterpret_cast<unsigned long long*>(smem + G2_LLIST_OFF);
+    if constexpr (LIST) {
+        const int staged = my_tiles < G2_MAX_SEQ ? my_tiles : G2_MAX_SEQ;
+        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[(lbid + idx * (int)gridDim.x) / a.ctiles];
+        __syncthreads();
+    }
 
     // ---- masked launches: tile coordinates and per-row pixel masks of THIS workgroup's tiles go to LDS once.  Read from global
     //      memory where they are used (a tile-map entry per tile change, a mask byte per stored row) every one of those loads
@@ -127,11 +143,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         __syncthreads();
     }
 
-    // tile seq -> (image, tile row, tile column, cout tile); cout tile fastest
-    auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct) {
+    // tile seq -> (image, tile row, tile column, cout tile); cout tile fastest.  ext (LIST): the crop's extents on the INPUT tensor
+    auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct, int& ext) {
         const int t = lbid + seq * (int)gridDim.x;
         ct = t % a.ctiles;
         const int p = t / a.ctiles;
+        if constexpr (LIST) {
+            const unsigned long long e = seq < G2_MAX_SEQ ? llist[seq] : a.list[p];
+            const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+            ext = __builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
+            n = lo >> 16;
+            ty = (lo >> 8) & 0xFF;
+            tx = lo & 0xFF;
+            return;
+        }
+        ext = 0;
         n = p / a.tiles_per_image;
         const int r = p - n * a.tiles_per_image;
         if (a.mask) {
@@ -147,8 +173,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // ---- patch DMA: piece j fills patch rows 8j .. 8j+7 (row = lane>>3, phys chunk = lane&7); pieces dealt
     //      round-robin to the 8 waves (wave w: pieces w, w+8, ...; 6 for w = 0, else 5) ----
     const int npp = (wc == 0) ? 6 : 5;
-    auto issue_patch = [&](int n, int ty, int tx, int c, int buf) {
+    auto issue_patch = [&](int n, int ty, int tx, int c, int buf, int ext) {
         const int y0 = ty * G2_T - 1, x0 = tx * G2_T - 1;
+        const int ey = ext >> 16, ex = ext & 0xFFFF;
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the volatile
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
@@ -162,24 +189,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 const int lchunk = (ln & 7) ^ g2_swz(py, px);
                 const int y = y0 + py, x = x0 + px;
                 const bool ok = pp < G2_NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                const unsigned off = (unsigned)((((size_t)(n * a.H + y) * a.W + x) * a.Cin + c * 64) * 2) + (unsigned)(lchunk * 16);
+                int nn = n;
+                if constexpr (LIST) nn = (y >= ey || x >= ex) ? a.N - 1 : n;    // constant region of the crop: the constant crop's pixel
+                const unsigned off = (unsigned)((((size_t)(nn * a.H + y) * a.W + x) * a.Cin + c * 64) * 2) + (unsigned)(lchunk * 16);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p, (lds_void*)(Ap + buf * G2_A_BYTES + j * 1024), 16,
                                                          (int)(ok ? off : 0xFFFFFFF0u), 0, 0, 0);
             }
         }
     };
     // patch issue pointer: the next flat chunk to fetch and its tile
-    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n, pi_ty, pi_tx, pi_ct;
-    tile_of(0, pi_n, pi_ty, pi_tx, pi_ct);
+    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext;
+    tile_of(0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext);
     auto issue_next_patch = [&]() {
         if (pi < total_chunks) {
-            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
+            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf, pi_ext);
             ++pi;
             if (++pi_buf == 3) pi_buf = 0;
             if (++pi_c == nchunks) {
                 pi_c = 0;
                 ++pi_seq;
-                if (pi_seq < my_tiles) tile_of(pi_seq, pi_n, pi_ty, pi_tx, pi_ct);
+                if (pi_seq < my_tiles) tile_of(pi_seq, pi_n, pi_ty, pi_tx, pi_ct, pi_ext);
             }
         }
     };
@@ -287,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
 
     // ---- prologue ----
-    int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct;
-    tile_of(0, t_n, t_ty, t_tx, t_ct);
+    int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct, t_ext_;
+    tile_of(0, t_n, t_ty, t_tx, t_ct, t_ext_);
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
@@ -447,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 for (int nt = 0; nt < NB; ++nt) acc[mt][nt] = nbias[mt];
             cchunk = 0;
             ++seq;
-            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct);
+            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
         } else {
             ++cchunk;
         }
@@ -472,20 +501,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #undef G2_LOAD_A
 }
 
-template <typename E, bool POOL, bool GMAX>
+template <typename E, bool POOL, bool GMAX, bool LIST = false>
 static int launch_halo2(Halo2Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 255) / 256;
     a.ntiles = a.ptiles * a.ctiles;
-    const int smem = a.mask ? G2_SMEM_MASKED : 3 * G2_A_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo2_kernel<E, POOL, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_MASKED) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    const int smem = a.mask ? G2_SMEM_MASKED : (LIST ? G2_SMEM_LIST : 3 * G2_A_BYTES);
+    if (!cvpce_smem_attr_done<conv3x3_halo2_kernel<E, POOL, GMAX, LIST>>((const void*)conv3x3_halo2_kernel<E, POOL, GMAX, LIST>, G2_SMEM_MASKED))
+        return CVPCE_ERR_LAUNCH;
     const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
     if (a.mask && (a.ntiles + grid - 1) / grid > G2_MAX_SEQ) return CVPCE_ERR_ARG;   // the workgroup's tile list lives in LDS
-    hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX, LIST>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
@@ -519,6 +544,7 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;
+    a.list = nullptr; a.list_count = nullptr;
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (gmax) return fuse_pool2 ? launch_halo2<E, true, true>(a, s) : launch_halo2<E, false, true>(a, s);
@@ -555,4 +581,39 @@ extern "C" int cvpce_conv3x3_halo_masked_f16(const void* in, const void* wgt, co
                                              int K_pad, int Cout_pad, int relu, void* stream) {
     if (!mask) return CVPCE_ERR_ARG;
     return halo2_dispatch<ElemF16>(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
+}
+
+// Work-list launch (bf16 only: the embedder).  Cout <= 128 is forwarded to the wide-tile kernel's list entry.
+int cvpce_conv3x3_halo_wide_list(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                                 int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, const unsigned long long* list,
+                                 const int* count_dev, void* stream);
+
+extern "C" int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                                       int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                                       int fuse_pool2, const unsigned long long* list, const int* count_dev, void* stream) {
+    if (N <= 0) return CVPCE_OK;
+    if (!in || !wgt || (!out && !mac) || !list || !count_dev) return CVPCE_ERR_ARG;
+    if (mac && (!relu || Cout <= 128 || mac_off < 0 || mac_off + Cout > mac_stride)) return CVPCE_ERR_ARG;
+    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
+    if (fuse_pool2 && ((H & 1) || (W & 1))) return CVPCE_ERR_ARG;
+    if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
+    if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
+    if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31) || N > 65535) return CVPCE_ERR_ARG;
+    if (Cout <= 128) return cvpce_conv3x3_halo_wide_list(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, list, count_dev, stream);
+    Halo2Args a;
+    a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)out;
+    a.gmax = mac; a.gmax_stride = mac_stride; a.gmax_off = mac_off;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
+    a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T;
+    if (a.tiles_x > 255 || a.tiles_y > 255 || H > 65535 || W > 65535) return CVPCE_ERR_ARG;
+    a.tile_map = nullptr; a.tiles_per_image = a.tiles_x * a.tiles_y;
+    a.ptiles = N * a.tiles_per_image;
+    a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+    a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
+    a.ctiles = a.ntiles = 0;
+    a.list = list; a.list_count = count_dev;
+    if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (mac) return fuse_pool2 ? launch_halo2<ElemBF16, true, true, true>(a, s) : launch_halo2<ElemBF16, false, true, true>(a, s);
+    return fuse_pool2 ? launch_halo2<ElemBF16, true, false, true>(a, s) : launch_halo2<ElemBF16, false, false, true>(a, s);
 }

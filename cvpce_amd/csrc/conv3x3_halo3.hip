@@ -29,6 +29,10 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define G3_NPIX (18 * 34)
 #define G3_NPIECE 39                       // 16 pixels of 64 B per 1-KiB DMA piece
 #define G3_A_BYTES (G3_NPIECE * 1024)
+// work-list launches (skiplist.hip): the first G3_MAX_SEQ entries of the workgroup's own list in LDS
+#define G3_MAX_SEQ 512
+#define G3_LLIST_OFF (3 * G3_A_BYTES)
+#define G3_SMEM_LIST (G3_LLIST_OFF + G3_MAX_SEQ * 8)
 
 __device__ __forceinline__ int g3_col(int l16) { return l16 < 4 ? 2 * l16 : (l16 >= 12 ? 2 * (l16 - 8) : 2 * (l16 - 4) + 1); }
 
@@ -40,6 +44,10 @@ struct Halo3Args {
     int N, H, W, Cin, Cout, K_pad, relu;
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
+    // LIST launches (see conv3x3_halo2.hip): the tiles to compute, *list_count entries; input pixels in the constant region of
+    // their crop are read from image N - 1
+    const unsigned long long* list;
+    const int* list_count;
 };
 
 // diagnostic build only (tools/ablate.sh conv3x3_halo3 128; tools/dev/halo3_stamps.py): s_memtime ticks two waves of one workgroup
@@ -58,7 +66,7 @@ extern "C" int cvpce_debug_halo3_stamps(unsigned long long* host_out) {
 #define G3_STAMP_STEP()
 #endif
 
-template <typename E, bool POOL>
+template <typename E, bool POOL, bool LIST>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #if CVPCE_DBG & 128
     unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
@@ -82,15 +90,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // fetched again from beyond it: conv2_1 +2.3 %, conv2_2 +1.8 % (same call, three alternations, real activations;
     // CVPCE_DBG & 2 = the plain order, dev A/B)
     const int lbid = (CVPCE_DBG & 2) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int my_tiles = (a.ntiles - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    int ntiles_ = a.ntiles;
+    if constexpr (LIST) ntiles_ = __builtin_amdgcn_readfirstlane(*a.list_count) * a.ctiles;
+    const int my_tiles = (ntiles_ - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
     if (my_tiles <= 0) return;
     const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
     const int total_sub = 2 * total_chunks;
+    unsigned long long* llist = reinterpret_cast<unsigned long long*>(smem + G3_LLIST_OFF);
+    if constexpr (LIST) {
+        const int staged = my_tiles < G3_MAX_SEQ ? my_tiles : G3_MAX_SEQ;
+        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[(lbid + idx * (int)gridDim.x) / a.ctiles];
+        __syncthreads();
+    }
 
-    auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct) {
+    auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct, int& ext) {
         const int t = lbid + seq * (int)gridDim.x;
         ct = t % a.ctiles;
         const int p = t / a.ctiles;
+        if constexpr (LIST) {
+            const unsigned long long e = seq < G3_MAX_SEQ ? llist[seq] : a.list[p];
+            const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+            ext = __builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
+            n = lo >> 16;
+            ty = (lo >> 8) & 0xFF;
+            tx = lo & 0xFF;
+            return;
+        }
+        ext = 0;
         n = p / (a.tiles_x * a.tiles_y);
         const int r = p - n * (a.tiles_x * a.tiles_y);
         ty = r / a.tiles_x;
@@ -100,8 +126,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // ---- patch DMA: piece j fills patch pixels 16j .. 16j+15 (pixel = lane>>2, phys chunk = lane&3); pieces dealt
     //      round-robin to the 8 waves (wave w: pieces w, w+8, ...: 5 for w < 7, else 4) ----
     const int npp = (wid < 7) ? 5 : 4;
-    auto issue_patch = [&](int n, int ty, int tx, int c32, int buf) {
+    auto issue_patch = [&](int n, int ty, int tx, int c32, int buf, int ext) {
         const int y0 = ty * G3_TH - 1, x0 = tx * G3_TW - 1;
+        const int ey = ext >> 16, ex = ext & 0xFFFF;
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the empty
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
@@ -115,25 +142,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                 const int lchunk = (ln & 3) ^ ((px >> 2) & 3);
                 const int y = y0 + py, x = x0 + px;
                 const bool ok = pp < G3_NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                const unsigned off = (unsigned)((((size_t)(n * a.H + y) * a.W + x) * a.Cin + c32 * 32) * 2) + (unsigned)(lchunk * 16);
+                int nn = n;
+                if constexpr (LIST) nn = (y >= ey || x >= ex) ? a.N - 1 : n;    // constant region of the crop: the constant crop's pixel
+                const unsigned off = (unsigned)((((size_t)(nn * a.H + y) * a.W + x) * a.Cin + c32 * 32) * 2) + (unsigned)(lchunk * 16);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p, (lds_void*)(Ap + buf * G3_A_BYTES + j * 1024), 16,
                                                          (int)(ok ? off : 0xFFFFFFF0u), 0, 0, 0);
             }
         }
     };
     // patch issue pointer: the next flat 32-channel sub-chunk to fetch and its tile
-    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n, pi_ty, pi_tx, pi_ct;
-    tile_of(0, pi_n, pi_ty, pi_tx, pi_ct);
+    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext;
+    tile_of(0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext);
     const int nsub = 2 * nchunks;
     auto issue_next_patch = [&]() {
         if (pi < total_sub) {
-            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf);
+            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf, pi_ext);
             ++pi;
             if (++pi_buf == 3) pi_buf = 0;
             if (++pi_c == nsub) {
                 pi_c = 0;
                 ++pi_seq;
-                if (pi_seq < my_tiles) tile_of(pi_seq, pi_n, pi_ty, pi_tx, pi_ct);
+                if (pi_seq < my_tiles) tile_of(pi_seq, pi_n, pi_ty, pi_tx, pi_ct, pi_ext);
             }
         }
     };
@@ -248,8 +277,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     }
 
     // ---- prologue ----
-    int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct;
-    tile_of(0, t_n, t_ty, t_tx, t_ct);
+    int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct, t_ext_;
+    tile_of(0, t_n, t_ty, t_tx, t_ct, t_ext_);
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
@@ -349,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
             G3_TOC(3)
             cchunk = 0;
             ++seq;
-            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct);
+            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
         } else {
             ++cchunk;
         }
@@ -373,25 +402,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #undef G3_LOAD_A
 }
 
-template <typename E, bool POOL>
+template <typename E, bool POOL, bool LIST = false>
 static int launch_halo3(Halo3Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 127) / 128;
     a.ntiles = a.ptiles * a.ctiles;
-    const int smem = 3 * G3_A_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_halo3_kernel<E, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    const int smem = LIST ? G3_SMEM_LIST : 3 * G3_A_BYTES;
+    if (!cvpce_smem_attr_done<conv3x3_halo3_kernel<E, POOL, LIST>>((const void*)conv3x3_halo3_kernel<E, POOL, LIST>, smem)) return CVPCE_ERR_LAUNCH;
     const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
-    hipLaunchKernelGGL((conv3x3_halo3_kernel<E, POOL>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<E, POOL, LIST>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
 template <typename E>
 static int halo3_dispatch(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
-                          int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
+                          int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream,
+                          const unsigned long long* list = nullptr, const int* count_dev = nullptr) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout % 8 != 0 || Cout <= 0) return CVPCE_ERR_ARG;
@@ -406,8 +431,13 @@ static int halo3_dispatch(const void* in, const void* wgt, const float* bias, vo
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;
+    a.list = list; a.list_count = count_dev;
     if ((long long)a.ptiles * ((Cout + 127) / 128) * (Cin / 64) >= (1LL << 29)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (list) {
+        if (E::kF16 || !count_dev || N > 65535 || a.tiles_x > 255 || a.tiles_y > 255 || H > 65535 || W > 65535) return CVPCE_ERR_ARG;   // (the list entry exists for the bf16 embedder)
+        if constexpr (!E::kF16) return fuse_pool2 ? launch_halo3<E, true, true>(a, s) : launch_halo3<E, false, true>(a, s);
+    }
     return fuse_pool2 ? launch_halo3<E, true>(a, s) : launch_halo3<E, false>(a, s);
 }
 
@@ -418,4 +448,12 @@ extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const fl
 extern "C" int cvpce_conv3x3_halo_wide_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,
                                            int Cin, int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream) {
     return halo3_dispatch<ElemF16>(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream);
+}
+
+// work-list launch (called by cvpce_conv3x3_halo_list for Cout <= 128; not part of the C ABI of its own)
+int cvpce_conv3x3_halo_wide_list(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
+                                 int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, const unsigned long long* list,
+                                 const int* count_dev, void* stream) {
+    if (!list || !count_dev) return CVPCE_ERR_ARG;
+    return halo3_dispatch<ElemBF16>(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, stream, list, count_dev);
 }

@@ -986,13 +986,8 @@ static int launch_conv_dma(const ConvArgs& a0, hipStream_t stream) {
     a.tiles_p = (a.M + TP - 1) / TP;
     a.tiles_c = (a.Cout + TC - 1) / TC;
     const size_t smem = (size_t)2 * (TC + TP) * 64 * sizeof(bf16_t);
-    static bool attr_set = false;     // one flag per template instance
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma_kernel<E, TC, TP, WC, WP, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!cvpce_smem_attr_done<conv_dma_kernel<E, TC, TP, WC, WP, MINW>>((const void*)conv_dma_kernel<E, TC, TP, WC, WP, MINW>, (int)smem))
+        return CVPCE_ERR_LAUNCH;     // (one flag per template instance and device)
     dim3 grid(a.tiles_p * a.tiles_c);
     hipLaunchKernelGGL((conv_dma_kernel<E, TC, TP, WC, WP, MINW>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();
@@ -1004,13 +999,8 @@ static int launch_conv_dma4(const ConvArgs& a0, hipStream_t stream) {
     a.tiles_p = (a.M + TP - 1) / TP;
     a.tiles_c = (a.Cout + TC - 1) / TC;
     const size_t smem = (size_t)NS * (TC + TP) * 32 * sizeof(bf16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma4_kernel<E, TC, TP, WC, WP, MINW, NS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!cvpce_smem_attr_done<conv_dma4_kernel<E, TC, TP, WC, WP, MINW, NS>>((const void*)conv_dma4_kernel<E, TC, TP, WC, WP, MINW, NS>, (int)smem))
+        return CVPCE_ERR_LAUNCH;
     dim3 grid(a.tiles_p * a.tiles_c);
     hipLaunchKernelGGL((conv_dma4_kernel<E, TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();
@@ -1022,13 +1012,8 @@ static int launch_conv_dma16(const ConvArgs& a0, hipStream_t stream) {
     a.tiles_p = (a.M + TP - 1) / TP;
     a.tiles_c = (a.Cout + TC - 1) / TC;
     const size_t smem = (size_t)NS * (TC + TP) * 32 * sizeof(bf16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_dma16_kernel<E, TC, TP, WC, WP, MINW, NS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!cvpce_smem_attr_done<conv_dma16_kernel<E, TC, TP, WC, WP, MINW, NS>>((const void*)conv_dma16_kernel<E, TC, TP, WC, WP, MINW, NS>, (int)smem))
+        return CVPCE_ERR_LAUNCH;
     dim3 grid(a.tiles_p * a.tiles_c);
     hipLaunchKernelGGL((conv_dma16_kernel<E, TC, TP, WC, WP, MINW, NS>), grid, dim3(WC * WP * 64), smem, stream, a);
     return cvpce_check_launch();

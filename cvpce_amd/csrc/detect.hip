@@ -556,13 +556,7 @@ extern "C" int cvpce_detect_postprocess(const float* const* logits, const float*
     n.s_boxes = s_boxes; n.s_scores = s_scores; n.s_labels = s_labels; n.s_off = s_off; n.s_total = s_total;
     n.mask = mask; n.out_boxes = out_boxes; n.out_scores = out_scores; n.out_labels = out_labels;
     n.out_count = out_count; n.out_conf_count = out_conf_count;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SORT_CAP * 8) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!cvpce_smem_attr_done<nms_sort_kernel>((const void*)nms_sort_kernel, SORT_CAP * 8)) return CVPCE_ERR_LAUNCH;
     hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(1024), SORT_CAP * 8, s, n);
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, N), dim3(64), 0, s, n);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(1024), 0, s, n);

@@ -385,16 +385,10 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
     a.part_i = (int*)((char*)workspace + ((size_t)Qn * a.tiles_g * k * 4 + 255) / 256 * 256);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(a.tiles_g * a.tiles_q);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)match_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 256) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)match_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4 + 2048 + 512) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)match_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!cvpce_smem_attr_done<match_kernel<true, 128>>((const void*)match_kernel<true, 128>, 2 * 2 * 128 * 256) ||
+        !cvpce_smem_attr_done<match_kernel<false, 128>>((const void*)match_kernel<false, 128>, 128 * 128 * 4 + 2048 + 512) ||
+        !cvpce_smem_attr_done<match_kernel<false, 64>>((const void*)match_kernel<false, 64>, 2 * (128 + 64) * 128))
+        return CVPCE_ERR_LAUNCH;
     if (is_f32) {
         size_t smem = (size_t)2 * 2 * 128 * 256;    // 128 KiB staging (>= 66 KiB epilogue image)
         hipLaunchKernelGGL((match_kernel<true, 128>), grid, dim3(256), smem, s, a);

@@ -175,13 +175,17 @@ __global__ void crop_resize_kernel(const float* __restrict__ img, const float* _
         float ly0, ly1, lx0, lx1;
         src_index(sc, oy, larger, yy0, yy1, ly0, ly1);
         src_index(sc, ox, larger, xx0, xx1, lx0, lx1);
+        // a pixel all four of whose taps are padding (yy0 >= ch or xx0 >= cw: the taps only move further out) is EXACTLY the
+        // pad constant -- the interpolation weights sum to 1 only up to an ulp; cvpce_crop_extents reports the same predicate
+        if (yy0 < ch && xx0 < cw) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* pl = img + (size_t)c * H0 * W0;
-            auto at = [&](int yy, int xx) -> float {
-                return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
-            };
-            v[c] = ly0 * (lx0 * at(yy0, xx0) + lx1 * at(yy0, xx1)) + ly1 * (lx0 * at(yy1, xx0) + lx1 * at(yy1, xx1));
+            for (int c = 0; c < 3; ++c) {
+                const float* pl = img + (size_t)c * H0 * W0;
+                auto at = [&](int yy, int xx) -> float {
+                    return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
+                };
+                v[c] = ly0 * (lx0 * at(yy0, xx0) + lx1 * at(yy0, xx1)) + ly1 * (lx0 * at(yy1, xx0) + lx1 * at(yy1, xx1));
+            }
         }
     }
     if (mode == 0) {
@@ -247,9 +251,11 @@ __global__ void crop_resize2_kernel(const float* __restrict__ img, const float* 
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
+            if (yy0 < ch && xx0[u] < cw) {                   // else: all four taps are padding -> exactly 0.5 (see crop_resize_kernel)
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                v[u][c] = ly0 * (lx0[u] * t[u][c][0] + lx1[u] * t[u][c][1]) + ly1 * (lx0[u] * t[u][c][2] + lx1[u] * t[u][c][3]);
+                for (int c = 0; c < 3; ++c)
+                    v[u][c] = ly0 * (lx0[u] * t[u][c][0] + lx1[u] * t[u][c][1]) + ly1 * (lx0[u] * t[u][c][2] + lx1[u] * t[u][c][3]);
+            }
     }
     const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
     bf16_t o[2][4];
@@ -295,6 +301,52 @@ extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int
     }
     hipLaunchKernelGGL(crop_resize_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, out, H0, W0,
                        S, mode, m[0], m[1], m[2], s[0], s[1], s[2]);
+    return cvpce_check_launch();
+}
+
+// Content extent of every crop at the crop resolution S (the embedder's constant-padding tile skipping, skiplist.hip):
+// ext[p] = (rows, cols) such that every output pixel with oy >= rows or ox >= cols is exactly the pad constant -- the predicate
+// under which crop_resize*_kernel writes the constant, evaluated with the same src_index.  Boxes beyond *count: (S, S).
+__global__ void crop_extents_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int max_boxes, int H0, int W0,
+                                    int S, int* __restrict__ ext) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= max_boxes) return;
+    int ey = S, ex = S;
+    if (!count || p < *count) {
+        const float* b = boxes + (size_t)p * 4;
+        long long x1 = (long long)b[0], y1 = (long long)b[1], x2 = (long long)b[2], y2 = (long long)b[3];
+        x1 = x1 < 0 ? 0 : (x1 > W0 ? W0 : x1);
+        x2 = x2 < 0 ? 0 : (x2 > W0 ? W0 : x2);
+        y1 = y1 < 0 ? 0 : (y1 > H0 ? H0 : y1);
+        y2 = y2 < 0 ? 0 : (y2 > H0 ? H0 : y2);
+        int cw = (int)(x2 - x1), ch = (int)(y2 - y1);
+        if (cw < 0) cw = 0;
+        if (ch < 0) ch = 0;
+        const int larger = cw > ch ? cw : ch;
+        if (larger > 0) {
+            const float sc = (float)larger / (float)S;
+            ey = ex = 0;
+            for (int o = 0; o < S; ++o) {                    // the first source index is monotone in o: count the content rows / columns
+                int i0, i1;
+                float l0, l1;
+                src_index(sc, o, larger, i0, i1, l0, l1);
+                if (i0 < ch) ey = o + 1;
+                if (i0 < cw) ex = o + 1;
+            }
+        } else {
+            ey = ex = 0;                                     // degenerate box: the whole crop is the constant
+        }
+    }
+    ext[2 * p] = ey;
+    ext[2 * p + 1] = ex;
+}
+
+extern "C" int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int H0, int W0, int S, int* ext_out,
+                                  void* stream) {
+    if (!boxes || !ext_out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
+    if (max_boxes <= 0) return CVPCE_OK;
+    hipLaunchKernelGGL(crop_extents_kernel, dim3((max_boxes + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, count_dev, max_boxes,
+                       H0, W0, S, ext_out);
     return cvpce_check_launch();
 }
 

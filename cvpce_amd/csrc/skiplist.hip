@@ -1,0 +1,107 @@
+// Work lists for the embedder's constant-padding tile skipping.
+//
+// `resize_for_classification` (/root/reference/cvpce/datautils.py:232-239) pads every crop to a square with the constant 0.5
+// (top-left anchored) before the bilinear resize to 256 x 256: a 2.6 : 1 box leaves 61 % of the embedder's input constant.  A
+// conv output whose receptive field lies wholly in that region does not depend on the crop: it equals the same pixel of the
+// all-padding crop (same kernel, same tile position, same K order => the same bits, image-border effects included).  So every
+// pass of the embedder carries ONE extra crop -- the all-padding "constant crop", the last image of every tensor -- and
+//   * a tile all of whose OUTPUT pixels lie in the constant region of its crop is not computed and not stored,
+//   * a kernel that reads an input pixel in the constant region of its crop reads the constant crop's pixel instead
+//     (conv3x3_halo2.hip / conv3x3_halo3.hip: the image index of the patch DMA's per-lane offset).
+// Constant region of a tensor at stride 2^sh of the crop: rows >= e_y or columns >= e_x with e = min(size, ceil(e0 / 2^sh) + g),
+// e0 = the crop's content extent (cvpce_crop_extents), g = the growth the host accumulates (+1 per 3x3 conv, halved upwards
+// by a pool: an upper bound of the true extent, the same formula on the producer's and the consumer's side of a tensor).
+//
+// This kernel turns the extents into one compacted, crop-major tile list per layer (device-resident counts: no host sync):
+//   entry = ((ey_in << 16 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
+#include "common.h"
+#include "../../include/cvpce_amd.h"
+
+#define SKL_MAX_LAYERS 16
+
+struct WorklistArgs {
+    const int* ext0;                 // [n - 1][2] content rows / columns at the crop resolution S; image n - 1 is the constant crop
+    int n, S, nl;
+    cvpce_skip_layer L[SKL_MAX_LAYERS];
+    unsigned long long* lists;       // [nl][stride]
+    long long stride;
+    int* counts;                     // [nl]
+};
+
+__device__ __forceinline__ int skl_extent(int e0, int S, int sh, int g, int size) {
+    if (e0 >= S) return size;
+    const int e = ((e0 + (1 << sh) - 1) >> sh) + g;
+    return e < size ? e : size;
+}
+
+__global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
+    __shared__ int s_cnt[1024];
+    __shared__ int s_base;
+    const cvpce_skip_layer L = a.L[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int tiles_y = (L.H + L.tile_h - 1) / L.tile_h, tiles_x = (L.W + L.tile_w - 1) / L.tile_w;
+    unsigned long long* list = a.lists + (long long)blockIdx.x * a.stride;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int n0 = 0; n0 < a.n; n0 += 1024) {
+        const int n = n0 + tid;
+        int ny = 0, nx = 0, eiy = 0, eix = 0;
+        if (n < a.n) {
+            const bool is_const = n == a.n - 1;
+            const int ey0 = is_const ? a.S : a.ext0[2 * n], ex0 = is_const ? a.S : a.ext0[2 * n + 1];
+            ny = tiles_y; nx = tiles_x;
+            if (L.skip) {
+                const int eoy = skl_extent(ey0, a.S, L.out_shift, L.out_grow, L.H), eox = skl_extent(ex0, a.S, L.out_shift, L.out_grow, L.W);
+                const int cy = (eoy + L.tile_h - 1) / L.tile_h, cx = (eox + L.tile_w - 1) / L.tile_w;   // tile row ty is computed iff ty * tile_h < eoy
+                ny = cy < tiles_y ? cy : tiles_y;
+                nx = cx < tiles_x ? cx : tiles_x;
+            }
+            eiy = skl_extent(ey0, a.S, L.in_shift, L.in_grow, L.in_H);
+            eix = skl_extent(ex0, a.S, L.in_shift, L.in_grow, L.in_W);
+        }
+        // exclusive scan of the per-crop tile counts (Hillis-Steele over the 1024 slots)
+        const int cnt = ny * nx;
+        s_cnt[tid] = cnt;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int v = tid >= d ? s_cnt[tid - d] : 0;
+            __syncthreads();
+            s_cnt[tid] += v;
+            __syncthreads();
+        }
+        const int base = s_base + s_cnt[tid] - cnt;
+        const int chunk_total = s_cnt[1023];
+        __syncthreads();
+        if (tid == 0) s_base += chunk_total;
+        // entries of this thread's crop; blockIdx.y splits the crops among workgroups (every workgroup runs the same scan)
+        if (n < a.n && (n % (int)gridDim.y) == (int)blockIdx.y) {
+            const unsigned long long hi = ((unsigned long long)(((unsigned)eiy << 16) | (unsigned)eix)) << 32;
+            for (int j = 0; j < cnt; ++j) {
+                const int ty = j / nx, tx = j - ty * nx;
+                list[base + j] = hi | (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && blockIdx.y == 0) a.counts[blockIdx.x] = s_base;
+}
+
+extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, const cvpce_skip_layer* layers, int n_layers,
+                                     unsigned long long* lists, long long list_stride, int* counts, void* stream) {
+    if (n_layers <= 0) return CVPCE_OK;
+    if (!ext0 && n_images > 1) return CVPCE_ERR_ARG;
+    if (!layers || !lists || !counts || n_layers > SKL_MAX_LAYERS || n_images <= 0 || n_images > 65535 || S <= 0 || S > 32767) return CVPCE_ERR_ARG;
+    WorklistArgs a;
+    a.ext0 = ext0; a.n = n_images; a.S = S; a.nl = n_layers; a.lists = lists; a.stride = list_stride; a.counts = counts;
+    for (int i = 0; i < n_layers; ++i) {
+        const cvpce_skip_layer& l = layers[i];
+        if (l.H <= 0 || l.W <= 0 || l.tile_h <= 0 || l.tile_w <= 0 || l.in_H <= 0 || l.in_W <= 0 || l.in_H > 65535 || l.in_W > 65535) return CVPCE_ERR_ARG;
+        if (l.in_shift < 0 || l.out_shift < 0 || l.in_shift > 15 || l.out_shift > 15 || l.in_grow < 0 || l.out_grow < 0) return CVPCE_ERR_ARG;
+        const long long ty = (l.H + l.tile_h - 1) / l.tile_h, tx = (l.W + l.tile_w - 1) / l.tile_w;
+        if (ty > 255 || tx > 255 || ty * tx * n_images > list_stride) return CVPCE_ERR_ARG;
+        a.L[i] = l;
+    }
+    const int split = n_images >= 64 ? 8 : 1;
+    hipLaunchKernelGGL(embed_worklists_kernel, dim3(n_layers, split), dim3(1024), 0, (hipStream_t)stream, a);
+    return cvpce_check_launch();
+}

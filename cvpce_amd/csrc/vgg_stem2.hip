@@ -49,6 +49,11 @@ struct Stem2Args {
     bf16_t* out;         // [N][H/2][W/2][64]
     int N, H, W;
     int tiles_x, tiles_y, ntiles;
+    // LIST launches (the embedder's constant-padding tile skipping, skiplist.hip): the tiles to compute, low word of an entry =
+    // (n << 16) | (ty << 8) | tx, *list_count entries; image N - 1 (the constant crop) is read from const_in, not from `in`
+    const unsigned long long* list;
+    const int* list_count;
+    const bf16_t* const_in;
 };
 
 // byte offset of 16-B chunk `chunk` of conv1_1-output patch pixel (py, px): the swizzle of conv3x3_halo2.hip, which makes
@@ -87,6 +92,7 @@ __device__ __forceinline__ void team_barrier(unsigned cnt_addr, unsigned& target
     asm volatile("" ::: "memory");
 }
 
+template <bool LIST>
 __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* W2 = smem;
@@ -118,10 +124,26 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
 
     // input patch staging: 400 pixels of 8 B, two per thread of the team (second one only for qtid < 144)
     unsigned long long preg[2];
-    auto load_patch = [&](int tile) {
-        const int n = tile / (a.tiles_x * a.tiles_y);
-        const int r = tile - n * (a.tiles_x * a.tiles_y);
-        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+    // work item -> (image, tile row, tile column): a list entry, or the flat tile index itself
+    auto decode = [&](unsigned e, int& n, int& ty, int& tx) {
+        if constexpr (LIST) {
+            n = (int)(e >> 16);
+            ty = (int)((e >> 8) & 0xFF);
+            tx = (int)(e & 0xFF);
+        } else {
+            n = (int)e / (a.tiles_x * a.tiles_y);
+            const int r = (int)e - n * (a.tiles_x * a.tiles_y);
+            ty = r / a.tiles_x;
+            tx = r - ty * a.tiles_x;
+        }
+    };
+    auto load_patch = [&](unsigned item) {
+        int n, ty, tx;
+        decode(item, n, ty, tx);
+        const bf16_t* img = a.in + (size_t)n * a.H * a.W * a.cstride;
+        if constexpr (LIST) {
+            if (n == a.N - 1) img = a.const_in;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int p = qtid + k * 256;
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
                 const int py = p / S2_P0, px = p - py * S2_P0;
                 const int y = ty * S2_T - 2 + py, x = tx * S2_T - 2 + px;
                 if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                    v = *reinterpret_cast<const unsigned long long*>(a.in + ((size_t)(n * a.H + y) * a.W + x) * a.cstride);
+                    v = *reinterpret_cast<const unsigned long long*>(img + ((size_t)y * a.W + x) * a.cstride);
             }
             preg[k] = v;
         }
@@ -145,8 +167,16 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
 
     const int stride = 2 * (int)gridDim.x;
     int tile = 2 * (int)blockIdx.x + team;
-    if (tile >= a.ntiles) return;                     // (team-uniform; the other team does not wait for this one)
-    load_patch(tile);
+    int ntiles = a.ntiles;
+    if constexpr (LIST) ntiles = __builtin_amdgcn_readfirstlane(*a.list_count);
+    if (tile >= ntiles) return;                       // (team-uniform; the other team does not wait for this one)
+    // the work items of this and the next two iterations (LIST: list entries, fetched two iterations ahead of their use)
+    auto item_at = [&](int t) -> unsigned {
+        if constexpr (LIST) return t < ntiles ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a.list[t]) : 0u;
+        return (unsigned)t;
+    };
+    unsigned it_cur = item_at(tile), it_next = item_at(tile + stride);
+    load_patch(it_cur);
     store_patch();
     team_barrier(cnt_addr, bar_target, lane);
 
@@ -180,14 +210,15 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
     }
 
     int it_ = -1;
-    for (; tile < a.ntiles; tile += stride) {
+    for (; tile < ntiles; tile += stride) {
         ++it_;
         S2_STAMP(0)
-        const int n = tile / (a.tiles_x * a.tiles_y);
-        const int rem = tile - n * (a.tiles_x * a.tiles_y);
-        const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        int n, ty, tx;
+        decode(it_cur, n, ty, tx);
         const int next = tile + stride;
-        if (next < a.ntiles) load_patch(next);          // global loads in flight under the conv1_1 phase
+        if (next < ntiles) load_patch(it_next);         // global loads in flight under the conv1_1 phase
+        it_cur = it_next;
+        it_next = item_at(next + stride);
         const bool border = ty == 0 || tx == 0 || ty == a.tiles_y - 1 || tx == a.tiles_x - 1;
 
         // ================= phase 1: conv1_1 on the 18x18 patch -> A1 =================
@@ -243,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
         S2_STAMP(1)
         team_barrier(cnt_addr, bar_target, lane);
         S2_STAMP(2)
-        if (next < a.ntiles) store_patch();             // IN is free again: stage the next tile's input
+        if (next < ntiles) store_patch();               // IN is free again: stage the next tile's input
 
         // ================= phase 2: conv1_2 (9 taps x 4 K-steps) out of LDS =================
         f32x16 acc[2][2];
@@ -334,10 +365,12 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
     }
 }
 
-extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
-                                    const float* b2, void* out, int N, int H, int W, void* stream) {
+static int stem_launch(const void* in_nhwc, int in_cstride, const void* const_in, const void* w1, const float* b1, const void* w2,
+                       const float* b2, void* out, int N, int H, int W, const unsigned long long* list, const int* count_dev,
+                       void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in_nhwc || !w1 || !b1 || !w2 || !b2 || !out) return CVPCE_ERR_ARG;
+    if (list && (!count_dev || !const_in || N > 65535 || H / S2_T > 255 || W / S2_T > 255)) return CVPCE_ERR_ARG;
     if (in_cstride != 4 && in_cstride != 8) return CVPCE_ERR_ARG;
     if (H % S2_T != 0 || W % S2_T != 0 || H <= 0 || W <= 0) return CVPCE_ERR_ARG;
     if ((long long)N * H * W >= (1LL << 31) / 4) return CVPCE_ERR_ARG;      // in-kernel pixel indices are 32-bit, byte offsets 64-bit
@@ -345,14 +378,27 @@ extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const v
     a.in = (const bf16_t*)in_nhwc; a.cstride = in_cstride; a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2;
     a.out = (bf16_t*)out; a.N = N; a.H = H; a.W = W;
     a.tiles_x = W / S2_T; a.tiles_y = H / S2_T; a.ntiles = N * a.tiles_x * a.tiles_y;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)vgg_stem2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_SMEM) != hipSuccess)
-            return CVPCE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    a.list = list; a.list_count = count_dev; a.const_in = (const bf16_t*)const_in;
     const int pairs = (a.ntiles + 1) / 2;
     const int grid = pairs < g_cvpce_persistent_wgs ? pairs : g_cvpce_persistent_wgs;       // one persistent workgroup (two teams) per CU
-    hipLaunchKernelGGL(vgg_stem2_kernel, dim3(grid), dim3(512), S2_SMEM, (hipStream_t)stream, a);
+    if (list) {
+        if (!cvpce_smem_attr_done<vgg_stem2_kernel<true>>((const void*)vgg_stem2_kernel<true>, S2_SMEM)) return CVPCE_ERR_LAUNCH;
+        hipLaunchKernelGGL(vgg_stem2_kernel<true>, dim3(grid), dim3(512), S2_SMEM, (hipStream_t)stream, a);
+    } else {
+        if (!cvpce_smem_attr_done<vgg_stem2_kernel<false>>((const void*)vgg_stem2_kernel<false>, S2_SMEM)) return CVPCE_ERR_LAUNCH;
+        hipLaunchKernelGGL(vgg_stem2_kernel<false>, dim3(grid), dim3(512), S2_SMEM, (hipStream_t)stream, a);
+    }
     return cvpce_check_launch();
+}
+
+extern "C" int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, const float* b1, const void* w2,
+                                    const float* b2, void* out, int N, int H, int W, void* stream) {
+    return stem_launch(in_nhwc, in_cstride, nullptr, w1, b1, w2, b2, out, N, H, W, nullptr, nullptr, stream);
+}
+
+extern "C" int cvpce_vgg_stem_fused_list(const void* in_nhwc, int in_cstride, const void* const_in, const void* w1, const float* b1,
+                                         const void* w2, const float* b2, void* out, int N, int H, int W,
+                                         const unsigned long long* list, const int* count_dev, void* stream) {
+    if (!list || !count_dev || !const_in) return CVPCE_ERR_ARG;
+    return stem_launch(in_nhwc, in_cstride, const_in, w1, b1, w2, b2, out, N, H, W, list, count_dev, stream);
 }

@@ -33,6 +33,10 @@ MAX_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 256))  # crops per ke
 FUSED_EMBED_BATCH = int(_os.environ.get('CVPCE_EMBED_BATCH', 768))
 FUSED_EMBED_MAX = int(_os.environ.get('CVPCE_EMBED_MAX', 960))     # largest pass the 32-bit tensor limits allow with the fused stem (conv2_x output: 960 * 128 * 128 * 128 < 2^31)
 FUSED_EMBED_BATCH = min(FUSED_EMBED_BATCH, FUSED_EMBED_MAX)        # (an over-large CVPCE_EMBED_BATCH would hit the kernels' 32-bit guards instead of splitting the pass)
+# Constant-padding tile skipping (csrc/skiplist.hip): `resize_for_classification` (datautils.py:232-239) pads every crop to a square
+# with 0.5, so the part of the 256 x 256 embedder input below / right of the box content is the same constant in every crop; conv
+# tiles whose receptive field lies inside it are not computed (bit-identical results: tests/test_gpu_skip.py).  A/B switch.
+SKIP_PADDING = _os.environ.get('CVPCE_SKIP_PADDING', '1') != '0'
 
 
 def _passes(n, step, longest):
@@ -102,17 +106,97 @@ class MACVGGEngine:
             self.plan = self.plan[2:]
         self.device = device
         self.embedding_size = model.embedding_size
+        self._skip_plans = {}      # input size -> the work-list schedule of `_embed_pass_skip` (None: this plan has no such schedule)
+        self._const_crops = {}     # (mean, std, channels, size) -> the all-padding crop
 
-    def embed_packed(self, x, eps=1e-8, want_bf16=False, batch=None):
+    # ---- constant-padding tile skipping --------------------------------------------------------------------------------------
+    def skip_plan(self, size):
+        """The work-list schedule for size x size inputs: [(kind, PackedConv | None, pool, mac)] with one `ops.skip_layer` each, or
+        None when this engine's plan is not stem + 3x3 halo convolutions with the MAC descriptors fused (then nothing is skipped).
+        Extent bookkeeping (include/cvpce_amd.h `cvpce_skip_layer`): a tensor at stride 2^sh of the crop is constant beyond
+        ceil(ext / 2^sh) + g; a 3x3 conv adds 1 to g, a 2x2 pool halves g upwards and adds 1 to sh."""
+        if size in self._skip_plans:
+            return self._skip_plans[size]
+        steps, layers = None, []
+        if self.stem is not None and size % 16 == 0 and size <= 1024:
+            steps = [('stem', None, True, False)]
+            h, sh, g = size // 2, 1, 1                       # conv1_1 (+1), conv1_2 (+1), pool1: ceil(2 / 2) = 1
+            layers.append(ops.skip_layer(h, h, 8, 8, sh, g, size, size, 0, 0, 1))
+            plan = self.plan + [('desc', None)]
+            i = 0
+            while steps is not None and i < len(plan):
+                kind, pc = plan[i]
+                if kind not in ('conv', 'conv_pool') or not (pc.cin_pad % 64 == 0 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
+                                                             and pc.cout % 8 == 0 and pc.cout > 64 and pc.dtype == ops.BF16):
+                    steps = None
+                    break
+                mac = kind == 'conv' and i + 1 < len(plan) and plan[i + 1][0] == 'desc' and pc.cout > 128 and ops.USE_FUSED_MAC
+                after = plan[i + 2][0] if i + 2 < len(plan) else None
+                pool = kind == 'conv_pool' or (mac and after == 'pool' and h % 2 == 0)
+                store = not mac or after is not None
+                th, tw = (16, 32) if pc.cout <= 128 else (16, 16)
+                og, osh, oh = g + 1, sh, h
+                if pool:
+                    th, tw, og, osh, oh = th // 2, tw // 2, (og + 1) // 2, sh + 1, h // 2
+                if not store:
+                    oh, th, tw = h, 16, 16
+                layers.append(ops.skip_layer(oh, oh, th, tw, osh, og, h, h, sh, g, 0 if mac else 1))
+                steps.append(('conv', pc, pool, mac, store))
+                i += (3 if pool else 2) if mac else 1
+                if not mac and i < len(plan) and plan[i][0] != 'conv' and plan[i][0] != 'conv_pool':
+                    steps = None                              # a stand-alone pool / descriptor: not this schedule
+                    break
+                h, sh, g = oh, osh, og
+                if h % 16 != 0 and i < len(plan):
+                    steps = None
+        self._skip_plans[size] = None if steps is None else (steps, layers)
+        return self._skip_plans[size]
+
+    def const_crop(self, mean, std, channels, size):
+        """The all-padding crop in the layout the crop kernel writes: made BY the crop kernel from a zero-area box, so its
+        pixels are the very constant the kernel writes to every padding pixel."""
+        key = (tuple(float(v) for v in mean), tuple(float(v) for v in std), int(channels), int(size))
+        if key not in self._const_crops:
+            img = torch.zeros((3, 1, 1), dtype=torch.float32, device=self.device)
+            box = torch.zeros((1, 4), dtype=torch.float32, device=self.device)
+            self._const_crops[key] = ops.crop_resize(img, box, size, mode=2 if channels == 4 else 1, mean=mean, std=std)[0].contiguous()
+        return self._const_crops[key]
+
+    def _embed_pass_skip(self, xb, ext, const_in, sched):
+        """One pass of the schedule over work lists: xb (n,S,S,c) + the constant crop as image n -> MAC descriptor (n,1024)."""
+        steps, layers = sched
+        n = xb.shape[0]
+        lists, counts = ops.embed_worklists(ext, n + 1, xb.shape[1], layers, (xb.shape[1] // 16) ** 2)
+        desc = torch.zeros((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
+        off = 0
+        t = ops.vgg_stem_list(xb, const_in, self.stem, lists[0], counts[0:1])
+        for li, (kind, pc, pool, mac, store) in enumerate(steps[1:], start=1):
+            t = ops.conv2d_list(t, pc, lists[li], counts[li:li + 1], act=1, pool=pool, mac=desc if mac else None, mac_off=off, store=store)
+            if mac:
+                off += pc.cout
+        return desc[:n]
+
+    def embed_packed(self, x, eps=1e-8, want_bf16=False, batch=None, ext=None, const_in=None):
         """x: (B,256,256,8) bf16, already normalised -> (B,1024) f32 unit-norm [, bf16 copy].
         batch: crops per pass of the kernel schedule (default MAX_EMBED_BATCH; a host that runs on fewer CUs passes that
-        CU count so that the persistent kernels' tile counts stay whole multiples of their grid)."""
+        CU count so that the persistent kernels' tile counts stay whole multiples of their grid).
+        ext (B,2) int32 + const_in (S,S,c): the crops' content extents (`ops.crop_extents`) and the all-padding crop
+        (`const_crop`) -- tiles that lie in a crop's constant padding are then skipped (bit-identical results)."""
         outs, outs_bf = [], []
         fused = batch is None and self.stem is not None and x.shape[1] * x.shape[2] <= INPUT_SIZE * INPUT_SIZE
         step = batch or (FUSED_EMBED_BATCH if fused else MAX_EMBED_BATCH)
         plan = self.plan + [('desc', None)]            # the second descriptor: amax of the last map (classification.py:48-49)
-        for s, e in _passes(x.shape[0], step, FUSED_EMBED_MAX if fused else step):
+        sched = self.skip_plan(x.shape[1]) if (SKIP_PADDING and ext is not None and const_in is not None and fused and x.shape[1] == x.shape[2]) else None
+        for s, e in _passes(x.shape[0], step, (FUSED_EMBED_MAX - (1 if sched else 0)) if fused else step):
             xb = x[s:e]
+            if sched is not None:
+                desc = self._embed_pass_skip(xb, ext[s:e], const_in, sched)
+                r = ops.l2_normalize(desc.contiguous(), eps, want_bf16)
+                if want_bf16:
+                    outs.append(r[0]); outs_bf.append(r[1])
+                else:
+                    outs.append(r)
+                continue
             desc = torch.zeros((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)   # (zeros: the fused MAC epilogue takes atomic maxima of values >= 0)
             off = 0
             if self.stem is not None:

@@ -109,12 +109,16 @@ class ConvProfile:
         return f'conv_igemm_kernel<{tc},128,{64 if bk64 else 32},{1 if tc == 32 else 2},{4 if tc == 32 else 2}>'
 
     def summary(self):
+        """per kernel: launches, algorithmic FLOPs (`flops`), EXECUTED FLOPs (`flops_executed`: work-list launches of the embedder
+        compute only the tiles on their list -- records carry (device count, FLOPs per listed tile) for those), milliseconds."""
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.records:
-            d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+        for rec in self.records:
+            name, flops, e0, e1 = rec[:4]
+            d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'flops_executed': 0.0, 'ms': 0.0})
             d['launches'] += 1
             d['flops'] += flops
+            d['flops_executed'] += float(rec[4].item()) * rec[5] if len(rec) > 4 else flops
             d['ms'] += e0.elapsed_time(e1)
         return out
 
@@ -364,6 +368,76 @@ def vgg_stem(x, ps):
     if prof is not None:
         e1.record()
         prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n * h * w, e0, e1))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# constant-padding tile skipping of the embedder (csrc/skiplist.hip; include/cvpce_amd.h)
+# ---------------------------------------------------------------------------
+def crop_extents(boxes, count, h0, w0, size=256, out=None):
+    """boxes (P,4) f32 device [+ count (1,) int32 device] -> (P,2) int32: content rows / columns of every crop that
+    `crop_resize` makes of them; pixels beyond are exactly the pad constant."""
+    _need_cuda(boxes, count)
+    boxes = boxes.to(torch.float32).contiguous()
+    if out is None:
+        out = torch.empty((boxes.shape[0], 2), dtype=torch.int32, device=boxes.device)
+    T.crop_extents(boxes, count, int(h0), int(w0), int(size), out)
+    return out
+
+
+def skip_layer(h, w, tile_h, tile_w, out_shift, out_grow, in_h, in_w, in_shift, in_grow, skip):
+    """One `cvpce_skip_layer` as the flat int list `embed_worklists` takes."""
+    return [int(v) for v in (h, w, tile_h, tile_w, out_shift, out_grow, in_h, in_w, in_shift, in_grow, skip)]
+
+
+def embed_worklists(ext0, n_images, size, layers, max_tiles):
+    """ext0 (n_images - 1, 2) int32 (the last image is the implied constant crop); layers: list of `skip_layer` ->
+    (lists (L, n_images * max_tiles) int64, counts (L,) int32), all on the device, no synchronisation."""
+    _need_cuda(ext0)
+    dev = ext0.device if ext0 is not None else torch.device('cuda', torch.cuda.current_device())
+    lists = torch.empty((len(layers), n_images * max_tiles), dtype=torch.int64, device=dev)
+    counts = torch.empty((len(layers),), dtype=torch.int32, device=dev)
+    T.embed_worklists(ext0, int(n_images), int(size), [v for l in layers for v in l], lists, counts)
+    return lists, counts
+
+
+def vgg_stem_list(x, const_in, ps, work, count):
+    """`vgg_stem` over a work list: x (N-1,H,W,4|8) + the constant crop const_in (H,W,c) -> (N,H/2,W/2,64)."""
+    _need_cuda(x, const_in, work, count)
+    assert x.dtype == BF16 and x.is_contiguous() and x.shape[3] in (4, 8) and const_in.is_contiguous()
+    n1, h, w, c = x.shape
+    out = torch.empty((n1 + 1, h // 2, w // 2, 64), dtype=BF16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.vgg_stem_fused_list(x, const_in, ps.w1, ps.b1, ps.w2, ps.b2, out, work, count)
+    if prof is not None:
+        e1.record()
+        prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n1 * h * w, e0, e1, count, ps.flops_per_pixel * 256))
+    return out
+
+
+def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True):
+    """3x3 / s1 / p1 conv (+ReLU, + fused MaxPool2d(2,2), + fused MAC descriptor) over a work list; x (N,H,W,Cin) with the
+    constant crop as image N - 1.  Returns the output tensor (None with store=False)."""
+    _need_cuda(x, work, count, mac)
+    assert x.dtype == BF16 and pc.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    assert pc.cin_pad % 64 == 0 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and pc.cout % 8 == 0 and pc.cout > 64
+    n, h, w, cin = x.shape
+    out = None
+    if store:
+        out = torch.empty((n, h // 2, w // 2, pc.cout) if pool else (n, h, w, pc.cout), dtype=BF16, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.conv3x3_halo_list(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), work, count)
+    if prof is not None:
+        e1.record()
+        wide = pc.cout <= 128
+        prof.records.append(('conv3x3_halo3_kernel' if wide else 'conv3x3_halo2_kernel', 2.0 * (n - 1) * h * w * pc.cout * 9 * pc.cin, e0, e1,
+                             count, 2.0 * 16 * (32 if wide else 16) * pc.cout * 9 * pc.cin))
     return out
 
 

@@ -291,11 +291,19 @@ class BatchedPipeline:
         n = len(images)
         # the fused VGG stem reads 4- or 8-channel pixels: 8-byte pixels halve what the crop kernel writes and the stem re-reads
         narrow = getattr(emb_eng, 'stem', None) is not None
+        mean, std = getattr(self.classifier.encoder, 'input_mean', TANH_MEAN), getattr(self.classifier.encoder, 'input_std', TANH_STD)
         crops = torch.empty((n * dpi, size, size, 4 if narrow else 8), dtype=torch.bfloat16, device=eng.device)
+        # content extents of the crops (the part of a crop beyond them is the pad constant of datautils.py:232-239: the embedder
+        # skips the tiles that lie in it) -- only for an encoder whose engine has the work-list schedule
+        skip = hasattr(emb_eng, 'skip_plan') and emb_eng.skip_plan(size) is not None
+        ext = torch.empty((n * dpi, 2), dtype=torch.int32, device=eng.device) if skip else None
         for i, img in enumerate(images):
-            ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=getattr(self.classifier.encoder, 'input_mean', TANH_MEAN),
-                            std=getattr(self.classifier.encoder, 'input_std', TANH_STD), count=conf_count[i:i + 1],
+            ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=mean, std=std, count=conf_count[i:i + 1],
                             out=crops[i * dpi:(i + 1) * dpi])
+            if skip:
+                ops.crop_extents(boxes[i], conf_count[i:i + 1], img.shape[1], img.shape[2], size, out=ext[i * dpi:(i + 1) * dpi])
+        self._ext = ext
+        self._const_in = emb_eng.const_crop(mean, std, crops.shape[3], size) if skip else None
         return crops
 
     def _select(self, crops, counts):
@@ -307,6 +315,8 @@ class BatchedPipeline:
         else:
             sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
             valid = crops.index_select(0, sel)
+            if self.__dict__.get('_ext') is not None:
+                self._ext = self._ext.index_select(0, sel)
         return valid, sel
 
     def _crop_embed_match(self, images, det_out, counts, embed_batch=None):
@@ -361,7 +371,10 @@ class BatchedPipeline:
         counts = pin[n].tolist()
         valid, sel = self._select(crops, counts)
         t2 = mark()
-        emb = self.classifier.encoder.engine().embed_packed(valid)
+        if self.__dict__.get('_ext') is not None:
+            emb = self.classifier.encoder.engine().embed_packed(valid, ext=self._ext, const_in=self._const_in)
+        else:
+            emb = self.classifier.encoder.engine().embed_packed(valid)
         t3 = mark()
         idx = self.classifier.match(emb)
         t4 = mark()

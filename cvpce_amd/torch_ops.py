@@ -173,6 +173,47 @@ def _crop_resize(img, boxes, count, out, size, mode, mean, std):
                                 _stream()), 'crop_resize')
 
 
+@_op('crop_extents(Tensor boxes, Tensor? count, int h0, int w0, int size, Tensor(a!) ext) -> ()')
+def _crop_extents(boxes, count, h0, w0, size, ext):
+    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or ext.dtype != torch.int32 or not ext.is_contiguous() or ext.numel() < 2 * boxes.shape[0]:
+        raise RuntimeError('crop_extents: boxes (P,4) float32, ext (P,2) int32, both contiguous')
+    check(lib.cvpce_crop_extents(_p(boxes), _p(count), boxes.shape[0], h0, w0, size, _p(ext), _stream()), 'cvpce_crop_extents')
+
+
+@_op('embed_worklists(Tensor? ext0, int n_images, int size, int[] layers, Tensor(a!) lists, Tensor(b!) counts) -> ()')
+def _embed_worklists(ext0, n_images, size, layers, lists, counts):
+    """layers: 11 ints per layer in the field order of `cvpce_skip_layer`; lists (n_layers, stride) int64; counts (n_layers,) int32."""
+    nf = len(_lib.SkipLayer._fields_)
+    nl = len(layers) // nf
+    if len(layers) != nl * nf or lists.dtype != torch.int64 or not lists.is_contiguous() or lists.shape[0] != nl or counts.dtype != torch.int32 \
+            or counts.numel() != nl or (ext0 is not None and (ext0.dtype != torch.int32 or not ext0.is_contiguous() or ext0.numel() < 2 * (n_images - 1))):
+        raise RuntimeError('embed_worklists: bad argument shapes / types')
+    arr = (_lib.SkipLayer * nl)(*[_lib.SkipLayer(*[int(v) for v in layers[i * nf:(i + 1) * nf]]) for i in range(nl)])
+    check(lib.cvpce_embed_worklists(_p(ext0), n_images, size, ctypes.cast(arr, ctypes.c_void_p), nl, _p(lists), lists.shape[1], _p(counts), _stream()),
+          'cvpce_embed_worklists')
+
+
+@_op('vgg_stem_fused_list(Tensor x, Tensor const_in, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out, Tensor work, Tensor count) -> ()')
+def _vgg_stem_fused_list(x, const_in, w1, b1, w2, b2, out, work, count):
+    """x (N-1,H,W,c) + const_in (H,W,c) -> out (N,H/2,W/2,64): image N-1 of the pass is the constant crop."""
+    n1, h, w, c = x.shape
+    if x.dtype != torch.bfloat16 or const_in.dtype != torch.bfloat16 or tuple(const_in.shape[-3:]) != (h, w, c) or out.shape[0] != n1 + 1 \
+            or work.dtype != torch.int64 or count.dtype != torch.int32:
+        raise RuntimeError('cvpce_vgg_stem_fused_list: bad argument shapes / types')
+    check(lib.cvpce_vgg_stem_fused_list(_p(x), c, _p(const_in), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), n1 + 1, h, w, _p(work), _p(count),
+                                        _stream()), 'cvpce_vgg_stem_fused_list')
+
+
+@_op('conv3x3_halo_list(Tensor x, Tensor weight, Tensor? bias, Tensor(a!)? out, Tensor(b!)? mac, int mac_off, int cout, int k_pad, '
+     'int cout_pad, int relu, int pool, Tensor work, Tensor count) -> ()')
+def _conv3x3_halo_list(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, relu, pool, work, count):
+    n, h, w, cin = x.shape
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or work.dtype != torch.int64 or count.dtype != torch.int32:
+        raise RuntimeError('cvpce_conv3x3_halo_list: bf16 activations, int64 work list, int32 count')
+    check(lib.cvpce_conv3x3_halo_list(_p(x), _p(weight), _p(bias), _p(out), _p(mac), mac.shape[1] if mac is not None else 0, mac_off, n, h, w,
+                                      cin, cout, k_pad, cout_pad, relu, pool, _p(work), _p(count), _stream()), 'cvpce_conv3x3_halo_list')
+
+
 @_op('pack_embed_input(Tensor images, Tensor(a!) out, int to_tanh, float[] mean, float[] std) -> ()')
 def _pack_embed_input(images, out, to_tanh, mean, std):
     check(lib.cvpce_pack_embed_input(_p(images), _p(out), images.shape[0], images.shape[2], to_tanh, _lib.float3(mean), _lib.float3(std),

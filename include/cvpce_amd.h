@@ -157,6 +157,49 @@ int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev
 int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int to_tanh, const float* mean3,
                            const float* std3, void* stream);
 
+/* ---- constant-padding tile skipping of the embedder ----------------------------------------------------------------------
+ * datautils.py:232-239 (`resize_for_classification`) pads every crop to a square with the constant 0.5, top-left anchored,
+ * before the resize to SxS: the part of a crop below / right of the box content is the same constant in every crop, and so is
+ * every conv output whose receptive field lies inside it (classification.py:38-51 is a stack of 3x3 convs, ReLUs and 2x2
+ * pools).  A pass of the embedder therefore carries one extra image -- the all-padding CONSTANT CROP, always the LAST image
+ * (index N - 1) of every tensor -- and the *_list entry points below (i) compute only the tiles of a work list and (ii) read an
+ * input pixel that lies in the constant region of its crop from the constant crop instead (it may never have been written).
+ * Results are bit-identical to the plain entry points: a skipped pixel would have been computed by the same kernel at the
+ * same tile position from the same operand bits as the constant crop's pixel.
+ *
+ * cvpce_crop_extents: ext_out[p] = (rows, cols) int32 pair per box, the content extent of crop p at the crop resolution S:
+ * cvpce_crop_resize writes EXACTLY the pad constant to every pixel with oy >= rows or ox >= cols.  p >= *count_dev: (S, S). */
+int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int H0, int W0, int S, int* ext_out,
+                       void* stream);
+/* One layer of the pass for cvpce_embed_worklists.  A tensor at stride 2^shift of the crop is constant on rows >= e_y /
+ * columns >= e_x with e = min(size, ceil(ext / 2^shift) + grow); `grow` is accumulated by the host (+1 per 3x3 conv; a 2x2
+ * pool halves it upwards and adds 1 to shift) and must be the same number wherever the same tensor is produced and consumed. */
+typedef struct {
+    int H, W;                  /* the layer's OUTPUT tensor (after a fused pool) */
+    int tile_h, tile_w;        /* the kernel's tile in output-tensor pixels (halo2 16x16, pooled 8x8; halo3 16x32, pooled 8x16; stem 8x8) */
+    int out_shift, out_grow;   /* extent formula of the output tensor */
+    int in_H, in_W;            /* the layer's INPUT tensor */
+    int in_shift, in_grow;     /* ... and its extent formula */
+    int skip;                  /* 0: list every tile (layers whose epilogue needs every tile: the fused MAC maximum) */
+} cvpce_skip_layer;
+/* ext0 [n_images - 1][2] (cvpce_crop_extents; the constant crop, image n_images - 1, is implied), layers [host] ->
+ * lists[l * list_stride + i] for i < counts[l] (device): the tiles layer l computes, crop-major,
+ *   entry = ((ey_in << 16 | ex_in) << 32) | (n << 16) | (ty << 8) | tx       (ey_in / ex_in: the INPUT tensor's extents of crop n)
+ * list_stride >= n_images * tiles of the largest layer.  No host synchronisation: the kernels read counts[l] themselves. */
+int cvpce_embed_worklists(const int* ext0, int n_images, int S, const cvpce_skip_layer* layers, int n_layers,
+                          unsigned long long* lists, long long list_stride, int* counts, void* stream);
+/* cvpce_vgg_stem_fused over a work list (tile = 8x8 output pixels).  `in` holds images 0 .. N-2, `const_in` (one image in the
+ * same layout) is read as image N - 1. */
+int cvpce_vgg_stem_fused_list(const void* in_nhwc, int in_cstride, const void* const_in, const void* w1, const float* b1,
+                              const void* w2, const float* b2, void* out, int N, int H, int W,
+                              const unsigned long long* list, const int* count_dev, void* stream);
+/* cvpce_conv3x3_halo / cvpce_conv3x3_halo_mac (mac != NULL: relu, MAC descriptor in the epilogue; out may then be NULL) over a
+ * work list; input pixels in the constant region of their crop are read from image N - 1.  Cout <= 128 runs the wide-tile
+ * kernel, mac needs Cout > 128. */
+int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                            int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                            int fuse_pool2, const unsigned long long* list, const int* count_dev, void* stream);
+
 /* RetinaNet.postprocess_detections + batched_nms + transform.postprocess (torchvision 0.9) and the
  * confidence-prefix count of production.py:15.  logits/regs/gh/gw/stride_* are [host] arrays of L
  * entries; logits[l] -> f32 [N][gh*gw*A*K], regs[l] -> f32 [N][gh*gw*A][4] (NHWC conv outputs).

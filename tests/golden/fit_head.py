@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Fit the RetinaNet head of the seeded synthetic detector on structured shelf scenes, so that detection AP against the
+TRUE product boxes is a non-vacuous figure.
+
+TEST INFRASTRUCTURE / DEV-ONLY GENERATOR (runs in the build container, minutes of CPU; nothing shipped imports it).
+The product of this script is the data fixture `tests/golden/fitted_head.pt`: the tensors of the trained head layers
+(reference state-dict key names) + the recipe that made them.  `tests/accuracy.py` loads them over
+`cvpce_amd.synthetic.synthetic_gln(seed=0)`.
+
+Why: with seeded random-init weights (no checkpoints offline, /root/reference/README.md:41-44) the detector finds no
+product -- AP50 against the pasted products' boxes is ~0.001 for every implementation, so north_star's "mAP within 0.1 pt"
+cannot be read against ground truth, only as agreement on a dense noise score field.  A detector whose HEAD is fitted to
+the scenes has a structured (bimodal) score field like a trained detector; the backbone + FPN stay at the seeded init.
+
+What is fitted (everything else stays frozen at the seeded init):
+    head.classification_head.conv.{4,6}, head.classification_head.cls_logits,
+    head.regression_head.conv.{4,6},     head.regression_head.bbox_reg
+with the RetinaNet training loss of torchvision 0.9 (the reference trains GLN with it,
+/root/reference/cvpce/models/proposals.py:162-168 -> RetinaNet.compute_loss): anchors matched to the true boxes at
+IoU >= 0.5 (foreground) / < 0.4 (background) / ignored in between, low-quality matches allowed; sigmoid focal loss
+(alpha 0.25, gamma 2) summed over non-ignored anchors / #foreground; L1 on the BoxCoder(1,1,1,1)-encoded deltas of
+the foreground anchors / #foreground.  Features of the frozen part (backbone, FPN, the first two tower convs) are computed
+once per scene by the fp32 oracle (oracle/gln.py) and cached; optimiser: Adam on the CPU.
+Scenes: cvpce_amd.synthetic.structured_shelf, seeds 50000+i (disjoint from the evaluation seeds 0..), at 2048^2 and
+1024^2 (tests/test_gpu_accuracy.py evaluates at 1024^2, the full-size report at 2048^2).
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+FIT_KEYS = ('head.classification_head.conv.4', 'head.classification_head.conv.6', 'head.classification_head.cls_logits',
+            'head.regression_head.conv.4', 'head.regression_head.conv.6', 'head.regression_head.bbox_reg')
+FROZEN_TOWER = (0, 2)       # tower convs evaluated once per scene (cached)
+FIT_TOWER = (4, 6)
+
+
+def box_iou(a, b):
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, None, :2], b[:, :2]); rb = torch.min(a[:, None, 2:], b[:, 2:])
+    inter = (rb - lt).clamp(min=0).prod(dim=2)
+    return inter / (area_a[:, None] + area_b - inter)
+
+
+def encode(gt, anchors):
+    """BoxCoder(weights=(1,1,1,1)).encode_single."""
+    aw, ah = anchors[:, 2] - anchors[:, 0], anchors[:, 3] - anchors[:, 1]
+    ax, ay = anchors[:, 0] + 0.5 * aw, anchors[:, 1] + 0.5 * ah
+    gw, gh = gt[:, 2] - gt[:, 0], gt[:, 3] - gt[:, 1]
+    gx, gy = gt[:, 0] + 0.5 * gw, gt[:, 1] + 0.5 * gh
+    return torch.stack(((gx - ax) / aw, (gy - ay) / ah, torch.log(gw / aw), torch.log(gh / ah)), dim=1)
+
+
+def match_anchors(gt, anchors, fg=0.5, bg=0.4):
+    """torchvision Matcher(fg, bg, allow_low_quality_matches=True) -> per anchor: gt index, -1 background, -2 ignored."""
+    iou = box_iou(gt, anchors)                       # (G, A)
+    best, idx = iou.max(dim=0)
+    out = idx.clone()
+    out[best < bg] = -1
+    out[(best >= bg) & (best < fg)] = -2
+    top = iou.max(dim=1, keepdim=True).values        # every true box keeps its best anchor(s)
+    lq = (iou == top).nonzero()[:, 1]
+    out[lq] = idx[lq]
+    return out
+
+
+def focal_sum(logits, targets, alpha=0.25, gamma=2.0):
+    p = torch.sigmoid(logits)
+    ce = F.binary_cross_entropy_with_logits(logits, targets, reduction='none')
+    pt = p * targets + (1 - p) * (1 - targets)
+    return ((alpha * targets + (1 - alpha) * (1 - targets)) * ce * (1 - pt) ** gamma).sum()
+
+
+@torch.no_grad()
+def scene_features(img, sd):
+    """Frozen part: transform -> backbone -> FPN -> the frozen tower convs of both towers.  -> (cls inputs, reg inputs) per level."""
+    from oracle import gln as og
+    x = og.transform_one(img)
+    batch = og.batch_images([x])
+    feats, _ = og.backbone_forward(batch, sd)
+    towers = []
+    for prefix in ('head.classification_head', 'head.regression_head'):
+        lv = []
+        for f in feats:
+            t = f
+            for i in FROZEN_TOWER:
+                t = F.relu(og.conv_b(t, sd, f'{prefix}.conv.{i}', padding=1))
+            lv.append(t)
+        towers.append(lv)
+    return towers, tuple(batch.shape[-2:]), [tuple(f.shape[-2:]) for f in feats], tuple(x.shape[-2:])
+
+
+def head_outputs(towers, params):
+    """The fitted layers over cached tower inputs -> (A_total,) logits, (A_total, 4) regressions in torchvision's anchor order."""
+    outs = []
+    for lv, prefix, final, k in ((towers[0], 'head.classification_head', 'cls_logits', 1), (towers[1], 'head.regression_head', 'bbox_reg', 4)):
+        per = []
+        for t in lv:
+            for i in FIT_TOWER:
+                t = F.relu(F.conv2d(t, params[f'{prefix}.conv.{i}.weight'], params[f'{prefix}.conv.{i}.bias'], padding=1))
+            o = F.conv2d(t, params[f'{prefix}.{final}.weight'], params[f'{prefix}.{final}.bias'], padding=1)
+            n, _, h, w = o.shape
+            per.append(o.view(n, -1, k, h, w).permute(0, 3, 4, 1, 2).reshape(-1, k))
+        outs.append(torch.cat(per))
+    return outs[0][:, 0], outs[1]
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--scenes', type=int, default=40)
+    ap.add_argument('--epochs', type=int, default=30)
+    ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--eval-images', type=int, default=6)
+    ap.add_argument('--out', default=os.path.join(HERE, 'fitted_head.pt'))
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 1)
+    from cvpce_amd import synthetic, metrics
+    from oracle import gln as og
+
+    t0 = time.perf_counter()
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=200)
+    sd = {k: v.clone() for k, v in det.state_dict().items()}
+    products = synthetic.product_images(1024, seed=200)          # = the first 1024 of tests/accuracy.py's product set
+    print(f'[fit] model + products ({time.perf_counter() - t0:.1f} s)', flush=True)
+
+    scenes = []
+    for i in range(a.scenes):
+        size = 2048 if i % 2 == 0 else 1024
+        img, gt, _ = synthetic.structured_shelf(50000 + i, size, size, products, pool=range(1000))
+        towers, padded_hw, grids, hw = scene_features(img, sd)
+        anchors = torch.cat(og.grid_anchors(padded_hw, grids))
+        gts = og.resize_boxes(gt, (size, size), hw)
+        m = match_anchors(gts, anchors)
+        scenes.append((towers, anchors, gts, m))
+        if i % 8 == 0:
+            print(f'[fit] scene {i}: {size}^2, {len(gt)} products, {int((m >= 0).sum())} foreground anchors ({time.perf_counter() - t0:.1f} s)', flush=True)
+
+    g = torch.Generator().manual_seed(4242)
+    params = {}
+    for key in FIT_KEYS:
+        w = torch.empty_like(sd[key + '.weight']).normal_(0, 0.01, generator=g)
+        b = torch.zeros_like(sd[key + '.bias'])
+        if key.endswith('cls_logits'):
+            b.fill_(-math.log((1 - 0.01) / 0.01))                # torchvision's prior-probability bias
+        params[key + '.weight'], params[key + '.bias'] = w.requires_grad_(), b.requires_grad_()
+    # the cached tower inputs have the scale of the random backbone's features: normalise the step size with Adam
+    opt = torch.optim.Adam(list(params.values()), lr=a.lr)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, a.epochs * len(scenes))
+    for ep in range(a.epochs):
+        order = torch.randperm(len(scenes), generator=g).tolist()
+        tot_c = tot_r = 0.0
+        for si in order:
+            towers, anchors, gts, m = scenes[si]
+            logits, reg = head_outputs(towers, params)
+            fgm, valid = m >= 0, m != -2
+            nfg = max(1, int(fgm.sum()))
+            loss_c = focal_sum(logits[valid], fgm[valid].float()) / nfg
+            loss_r = F.l1_loss(reg[fgm], encode(gts[m[fgm]], anchors[fgm]), reduction='sum') / nfg
+            opt.zero_grad(set_to_none=True)
+            (loss_c + loss_r).backward()
+            opt.step(); sched.step()
+            tot_c += float(loss_c); tot_r += float(loss_r)
+        print(f'[fit] epoch {ep}: focal {tot_c / len(scenes):.4f}  l1 {tot_r / len(scenes):.4f}  ({time.perf_counter() - t0:.1f} s)', flush=True)
+
+    fitted = {k: v.detach().clone() for k, v in params.items()}
+    sd.update(fitted)
+    # ---- evaluation with the oracle on the evaluation seeds of tests/accuracy.py (seed 0: 1000 * 0 + i) ----
+    rep = {}
+    for size in (2048, 1024):
+        tg, pb, ps, nconf = [], [], [], []
+        for i in range(a.eval_images):
+            img, gt, _ = synthetic.structured_shelf(i, size, size, products, pool=range(1000))
+            r = og.gln_forward([img], sd, detections_per_img=200)[0]
+            tg.append(gt); pb.append(r['boxes']); ps.append(r['scores']); nconf.append(int((r['scores'] > 0.5).sum()))
+        res = metrics.calculate_metrics(tg, pb, ps, iou_thresholds=(0.5, 0.75))
+        rep[size] = {'ap50': float(res[0.5]['ap']), 'ap75': float(res[0.75]['ap']), 'ar300': float(res[0.5]['ar_300']),
+                     'confident_per_image': nconf, 'products_per_image': [len(t) for t in tg]}
+        print(f'[fit] oracle on {a.eval_images} evaluation scenes of {size}^2: {rep[size]}', flush=True)
+    torch.save({'tensors': fitted,
+                'recipe': {'script': 'tests/golden/fit_head.py', 'scenes': a.scenes, 'epochs': a.epochs, 'lr': a.lr, 'base': 'synthetic_gln(seed=0)',
+                           'fit_keys': list(FIT_KEYS), 'oracle_eval': rep}}, a.out)
+    print(f'[fit] wrote {a.out} ({os.path.getsize(a.out) / 1e6:.1f} MB, {time.perf_counter() - t0:.0f} s)', flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,219 @@
+"""Constant-padding tile skipping of the embedder (csrc/skiplist.hip, the *_list entry points of include/cvpce_amd.h).
+
+`resize_for_classification` (/root/reference/cvpce/datautils.py:232-239) pads every crop to a square with 0.5; the embedder
+(/root/reference/cvpce/models/classification.py:38-51) then spends its time on that constant.  The work-list kernels skip the
+tiles that lie in it.  The bar: results BIT-IDENTICAL to the plain kernels, for any mix of box shapes."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+S = 256
+
+
+def _boxes(n, h0, w0, seed, kinds=('wide', 'tall', 'square', 'thin', 'tiny', 'edge', 'huge')):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        kind = kinds[i % len(kinds)]
+        r = lambda a, b: a + (b - a) * float(torch.rand(1, generator=g))
+        if kind == 'wide':
+            w, h = r(80, 400), r(20, 150)
+        elif kind == 'tall':
+            w, h = r(20, 150), r(80, 400)
+        elif kind == 'square':
+            w = h = r(30, 300)
+        elif kind == 'thin':
+            w, h = (r(200, 500), r(2, 12)) if i % 2 else (r(2, 12), r(200, 500))
+        elif kind == 'tiny':
+            w, h = r(1.2, 6), r(1.2, 6)
+        elif kind == 'huge':
+            w, h = r(0.6 * w0, 1.2 * w0), r(0.3 * h0, 0.9 * h0)
+        else:
+            w, h = r(50, 200), r(50, 200)
+        x1, y1 = r(0, w0 - 2), r(0, h0 - 2)
+        if kind == 'edge':
+            x1, y1 = w0 - w / 2, h0 - h / 2           # sticks out of the image: the slice clamps
+        out.append([x1, y1, x1 + w, y1 + h])
+    return torch.tensor(out, dtype=torch.float32)
+
+
+def _src_index(scale, dst, in_size):
+    """preproc.hip src_index in fp32 (PyTorch area_pixel_compute_source_index, align_corners=False)."""
+    s = torch.tensor(scale, dtype=torch.float32) * (torch.tensor(float(dst), dtype=torch.float32) + 0.5) - 0.5
+    s = max(float(s), 0.0)
+    return min(int(s), in_size - 1)
+
+
+def _extents_model(boxes, h0, w0):
+    out = []
+    for b in boxes.tolist():
+        x1, y1, x2, y2 = [int(v) for v in b]                     # .to(long)
+        x1, x2 = min(max(x1, 0), w0), min(max(x2, 0), w0)
+        y1, y2 = min(max(y1, 0), h0), min(max(y2, 0), h0)
+        cw, ch = max(x2 - x1, 0), max(y2 - y1, 0)
+        larger = max(cw, ch)
+        if larger == 0:
+            out.append([0, 0])
+            continue
+        sc = float(torch.tensor(float(larger), dtype=torch.float32) / torch.tensor(float(S), dtype=torch.float32))
+        i0 = [_src_index(sc, o, larger) for o in range(S)]
+        out.append([sum(1 for v in i0 if v < ch), sum(1 for v in i0 if v < cw)])
+    return torch.tensor(out, dtype=torch.int32)
+
+
+def test_crop_extents_and_exact_padding(cuda):
+    from cvpce_amd import ops
+    from cvpce_amd.models.classification import TANH_MEAN, TANH_STD
+    h0, w0 = 600, 800
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(3, h0, w0, generator=g).cuda()
+    boxes = _boxes(70, h0, w0, seed=11)
+    ext = ops.crop_extents(boxes.cuda(), None, h0, w0, S).cpu()
+    assert torch.equal(ext, _extents_model(boxes, h0, w0))
+    assert (ext[:, 0] < S).any() and (ext[:, 1] < S).any() and ((ext[:, 0] == S) & (ext[:, 1] == S)).any()
+    for mode, c in ((2, 4), (1, 8)):
+        crops = ops.crop_resize(img, boxes.cuda(), S, mode=mode, mean=TANH_MEAN, std=TANH_STD).cpu().view(torch.int16)
+        const = ops.crop_resize(torch.zeros(3, 1, 1).cuda(), torch.zeros(1, 4).cuda(), S, mode=mode, mean=TANH_MEAN, std=TANH_STD).cpu().view(torch.int16)[0]
+        assert (const == const[0, 0]).all()                      # one pixel value everywhere
+        for p in range(len(boxes)):
+            ey, ex = ext[p].tolist()
+            assert (crops[p, ey:] == const[ey:]).all() and (crops[p, :, ex:] == const[:, ex:]).all(), (p, boxes[p], ey, ex)
+    # mode 0 (the reference-shaped f32 crops): padding pixels are exactly 0.5
+    f = ops.crop_resize(img, boxes.cuda(), S, mode=0).cpu()
+    for p in range(len(boxes)):
+        ey, ex = ext[p].tolist()
+        assert (f[p, :, ey:] == 0.5).all() and (f[p, :, :, ex:] == 0.5).all()
+    # boxes beyond the device-side count: full extent
+    cnt = torch.tensor([5], dtype=torch.int32).cuda()
+    e2 = ops.crop_extents(boxes.cuda(), cnt, h0, w0, S).cpu()
+    assert torch.equal(e2[:5], ext[:5]) and (e2[5:] == S).all()
+
+
+def _extent(e0, sh, g, size):
+    if e0 >= S:
+        return size
+    return min(size, -(-e0 // (1 << sh)) + g)
+
+
+def test_worklists_match_python_model(cuda):
+    from cvpce_amd import ops, synthetic
+    enc = synthetic.synthetic_macvgg(seed=1).cuda()
+    steps, layers = enc.engine().skip_plan(S)
+    assert len(layers) == 12 and [l[-1] for l in layers] == [1] * 8 + [0] + [1, 1] + [0]      # conv4_3 / conv5_3 carry the MAC maximum: never skipped
+    g = torch.Generator().manual_seed(3)
+    n = 131
+    ext = torch.stack((torch.randint(1, S + 1, (n,), generator=g), torch.full((n,), S)), dim=1).to(torch.int32)
+    ext[::3] = ext[::3].flip(1)                                  # tall boxes: columns
+    ext[5] = torch.tensor([S, S]); ext[6] = torch.tensor([0, 0]); ext[7] = torch.tensor([1, S]); ext[8] = torch.tensor([S, 255])
+    lists, counts = ops.embed_worklists(ext.cuda(), n + 1, S, layers, 256)
+    lists, counts = lists.cpu(), counts.cpu().tolist()
+    allext = ext.tolist() + [[S, S]]
+    for li, L in enumerate(layers):
+        h, w, th, tw, osh, og, ih, iw, ish, ig, skip = L
+        ty_n, tx_n = -(-h // th), -(-w // tw)
+        want = []
+        for c, (ey0, ex0) in enumerate(allext):
+            ny, nx = ty_n, tx_n
+            if skip:
+                ny = min(ty_n, -(-_extent(ey0, osh, og, h) // th))
+                nx = min(tx_n, -(-_extent(ex0, osh, og, w) // tw))
+            hi = (_extent(ey0, ish, ig, ih) << 16) | _extent(ex0, ish, ig, iw)
+            want += [(hi << 32) | (c << 16) | (ty << 8) | tx for ty in range(ny) for tx in range(nx)]
+        assert counts[li] == len(want), (li, counts[li], len(want))
+        assert lists[li, :len(want)].tolist() == want, li
+    # the growth bookkeeping is an upper bound of the true extent of every tensor of the pass (a pixel beyond it is constant)
+    for e0 in range(1, S + 1):
+        true = e0
+        for li, L in enumerate(layers):
+            h, w, th, tw, osh, og, ih, iw, ish, ig, skip = L
+            assert _extent(e0, ish, ig, ih) >= min(ih, true), (li, e0)
+            if li == 0:
+                true = -(-(true + 2) // 2)                      # conv1_1, conv1_2, pool1
+            else:
+                pooled = h * 2 == ih
+                true = -(-(true + 1) // 2) if pooled else true + 1
+            true = min(true, h)
+            assert _extent(e0, osh, og, h) >= true, (li, e0)
+
+
+@pytest.mark.parametrize('batch_norm', [False, True])
+def test_embedding_is_bit_identical_with_skipping(cuda, batch_norm):
+    from cvpce_amd import ops, synthetic
+    from cvpce_amd.models import classification as C
+    enc = synthetic.synthetic_macvgg(seed=1, batch_norm=batch_norm).cuda()
+    eng = enc.engine()
+    h0, w0 = 700, 900
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(3, h0, w0, generator=g).cuda()
+    boxes = _boxes(83, h0, w0, seed=21).cuda()
+    crops = ops.crop_resize(img, boxes, S, mode=2, mean=C.TANH_MEAN, std=C.TANH_STD)
+    ext = ops.crop_extents(boxes, None, h0, w0, S)
+    const = eng.const_crop(C.TANH_MEAN, C.TANH_STD, 4, S)
+    plain = eng.embed_packed(crops)
+    prof = ops.PROFILE = ops.ConvProfile()
+    try:
+        skipped = eng.embed_packed(crops, ext=ext, const_in=const)
+        summ = prof.summary()
+    finally:
+        ops.PROFILE = None
+    assert torch.equal(plain, skipped)
+    done = sum(v['flops_executed'] for v in summ.values()); alg = sum(v['flops'] for v in summ.values())
+    assert done < 0.9 * alg, (done, alg)                         # something was skipped
+    # ... and with the switch off nothing is
+    C.SKIP_PADDING = False
+    try:
+        assert torch.equal(eng.embed_packed(crops, ext=ext, const_in=const), plain)
+    finally:
+        C.SKIP_PADDING = True
+    # NHWC8 input (the layout of Classifier.classify): same result
+    crops8 = ops.crop_resize(img, boxes, S, mode=1, mean=C.TANH_MEAN, std=C.TANH_STD)
+    assert torch.equal(eng.embed_packed(crops8, ext=ext, const_in=eng.const_crop(C.TANH_MEAN, C.TANH_STD, 8, S)), plain)
+    # extents that claim less padding than there is are still exact (conservative is always valid)
+    loose = torch.minimum(ext + 37, torch.full_like(ext, S))
+    assert torch.equal(eng.embed_packed(crops, ext=loose, const_in=const), plain)
+
+
+def test_multi_pass_and_all_padding(cuda):
+    """More crops than one pass of the schedule takes (the constant crop rides at the end of EVERY pass), all of one shape like
+    the bench's workload, plus degenerate boxes (an all-padding crop: every tile is skipped)."""
+    from cvpce_amd import ops, synthetic
+    from cvpce_amd.models import classification as C
+    enc = synthetic.synthetic_macvgg(seed=1).cuda()
+    eng = enc.engine()
+    h0 = w0 = 512
+    img = torch.rand(3, h0, w0, generator=torch.Generator().manual_seed(2)).cuda()
+    g = torch.Generator().manual_seed(4)
+    n = C.FUSED_EMBED_BATCH + 70
+    x1 = torch.rand(n, generator=g) * 200; y1 = torch.rand(n, generator=g) * 300
+    boxes = torch.stack((x1, y1, x1 + 260, y1 + 100), dim=1)
+    boxes[3] = torch.tensor([10.0, 10.0, 10.5, 90.0])            # zero width after .to(long)
+    boxes = boxes.cuda()
+    crops = ops.crop_resize(img, boxes, S, mode=2, mean=C.TANH_MEAN, std=C.TANH_STD)
+    ext = ops.crop_extents(boxes, None, h0, w0, S)
+    assert ext[3].tolist() == [S, 0]                              # no content column: the whole crop is the constant
+    const = eng.const_crop(C.TANH_MEAN, C.TANH_STD, 4, S)
+    assert torch.equal(eng.embed_packed(crops), eng.embed_packed(crops, ext=ext, const_in=const))
+
+
+def test_pipeline_results_identical_with_and_without_skipping(cuda):
+    from cvpce_amd import production, synthetic
+    from cvpce_amd.models import classification as C
+    dev = torch.device('cuda:0')
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=60).to(dev)
+    enc = synthetic.synthetic_macvgg(seed=1).to(dev)
+    gal = synthetic.gallery_images(48, seed=100)
+    clf = production.Classifier(enc, synthetic.TensorGallery(gal), device=dev, emb_device=dev, batch_size=16, match_dtype=torch.bfloat16)
+    imgs = [synthetic.shelf_image(40 + i, 640, 768).to(dev) for i in range(2)]
+    pipe = production.BatchedPipeline(det, clf, 0.5)
+    on = pipe.run(imgs)
+    C.SKIP_PADDING = False
+    try:
+        off = pipe.run(imgs)
+    finally:
+        C.SKIP_PADDING = True
+    assert int(on['count'].sum()) > 0
+    for k in ('boxes', 'scores', 'indices', 'embeddings', 'count'):
+        assert torch.equal(on[k], off[k]), k
