@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--no-peaks', action='store_true', help='skip the measured-peak microbenchmarks (library GEMM, device copy, bare MFMA loop)')
     ap.add_argument('--no-parity', action='store_true', help='skip the bounded HIP-vs-oracle accuracy sample')
     ap.add_argument('--no-h2d', action='store_true', help='skip the H2D-inclusive leg')
+    ap.add_argument('--no-precision-leg', action='store_true', help='skip the extra timed window in the other detector precision')
     return ap.parse_args()
 
 
@@ -220,26 +221,39 @@ def stage_gflop(stage, n_img, proposals, gallery):
 def conv_roofline(summ, stages=None):
     """`roofline` object from an ops.ConvProfile summary: the dominant kernel against the dense bf16 MFMA peak."""
     name, dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
-    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    # EXECUTED FLOPs over time: the embedder's work-list launches skip the tiles that lie in a crop's constant padding
+    # (csrc/skiplist.hip), so the algorithmic FLOPs of a layer are not all performed -- the roofline fraction prices what ran
+    achieved = dom.get('flops_executed', dom['flops']) / (dom['ms'] * 1e-3) / 1e12
     # HBM bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the figure measured
     # by the same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (two passes, gfx950 FETCH x2
     # correction) and committed under profiles/; null if no profile covers the kernel
     traffic = None
+    traffic_note = None
     try:
         prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
         v = prof.get(name)            # keyed by the names ops.ConvProfile uses (tools/summarise_profiles.py)
-        if v is not None:
+        # the file is stamped with the sha256 of the library it was collected on: figures of another build are not reported
+        from cvpce_amd import _lib
+        sha = hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+        if prof.get('_library_sha256') != sha:
+            traffic_note = 'profiles/hbm_traffic.json was collected on another build of libcvpce_hip.so: not reported'
+        elif v is not None:
             traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
     except Exception:
         traffic = None
     out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/)',
            'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
-           'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4)}
+           'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4),
+           'flops': 'EXECUTED (tiles on the work lists; the skipped constant-padding tiles are not counted)',
+           'algorithmic_tflops': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
+    if traffic_note:
+        out['traffic_note'] = traffic_note
     if stages is not None:
         out['stages'] = stages
     out['all_conv_kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                   'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+                                   'tflops': round(v.get('flops_executed', v['flops']) / (v['ms'] * 1e-3) / 1e12, 2),
+                                   'algorithmic_tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
     return out
 
 
@@ -374,6 +388,21 @@ def run_pipeline(args, rank, local_rank, world, dev):
     out = outs[0]
     proposals = float(sum(out['counts_host'])) / max(1, len(images))
 
+    # the same step with the detector in its OTHER storage mode (fp16 = the accuracy mode that meets the parity tolerance,
+    # DESIGN.md 2a; bf16 = the type BASELINE's configs name): one more timed window on rank 0
+    by_precision = None
+    if rank == 0 and not args.no_precision_leg:
+        other = 'fp16' if args.detector_precision == 'bf16' else 'bf16'
+        det2 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=other).to(dev)
+        pipe2 = production.BatchedPipeline(det2, clf, 0.5)
+        for _ in range(max(2, args.warmup)):
+            pipe2.run(images)
+        t2, _ = timed_windows(lambda: pipe2.run(images), args.steps, 1, dev, collective=False)
+        by_precision = {args.detector_precision: round(ipg * args.steps / elapsed, 3), other: round(ipg * args.steps / t2, 3),
+                        'note': 'images/s per GPU with the detector storing bf16 / fp16; the second figure is one extra timed window of '
+                                '--steps steps on rank 0 right after the headline windows, same box, same images'}
+        del pipe2, det2
+
     verify = None
     if args.verify:
         merged = gather_digests([(g, image_digest(out, i)) for i, g in enumerate(ids)], world)
@@ -398,6 +427,8 @@ def run_pipeline(args, rank, local_rank, world, dev):
             pipe.run(images)
         summ = ops.PROFILE.summary()
         ops.PROFILE = None
+        alg_conv = sum(v['flops'] for v in summ.values()) / args.steps / 1e9
+        exe_conv = sum(v.get('flops_executed', v['flops']) for v in summ.values()) / args.steps / 1e9
         stage_events = []                 # a separate pass: the per-launch events above slow the small detector launches
         for _ in range(args.steps):
             pipe.run(images, stage_events)
@@ -406,10 +437,27 @@ def run_pipeline(args, rank, local_rank, world, dev):
         for nm in ('detect', 'crop', 'embed', 'match'):
             ms = sum(a.elapsed_time(b) for n_, a, b in stage_events if n_ == nm) / args.steps
             gf = stage_gflop(nm, len(images), proposals, args.gallery)
-            stages[nm] = {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1),
-                          'tflops': round(gf / ms, 1) if ms > 0 else None,
-                          'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None}
+            ex = gf - (alg_conv - exe_conv) if nm == 'embed' else gf       # only the embedder's launches skip tiles
+            stages[nm] = {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1), 'executed_gflop': round(ex, 1),
+                          'tflops': round(ex / ms, 1) if ms > 0 else None,
+                          'frac_of_mfma_peak': round(ex / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None,
+                          'algorithmic_tflops': round(gf / ms, 1) if ms > 0 else None}
         roofline = conv_roofline(summ, stages)
+        alg_step = sum(stage_gflop(nm, len(images), proposals, args.gallery) for nm in ('detect', 'embed', 'match'))
+        roofline['gflop_per_step'] = {
+            'algorithmic': round(alg_step, 1), 'executed': round(alg_step - (alg_conv - exe_conv), 1),
+            'note': 'algorithmic = SURVEY.md 8(d) (298.4 GFLOP detector + 40.09 GFLOP per crop + matcher); executed = without the embedder tiles '
+                    'that lie in the crops\' constant 0.5-padding (datautils.py:232-239) and are skipped, results bit-identical; `tflops` / `frac` '
+                    'figures of this object are EXECUTED work over time, `algorithmic_tflops` the algorithmic work over the same time'}
+        roofline['end_to_end'] = {'executed_tflops': round((alg_step - (alg_conv - exe_conv)) / (elapsed / args.steps * 1e3), 1),
+                                  'frac_of_mfma_peak': round((alg_step - (alg_conv - exe_conv)) / (elapsed / args.steps * 1e3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                                  'algorithmic_tflops': round(alg_step / (elapsed / args.steps * 1e3), 1)}
+        # shape of the crops of this step (the padding a crop carries is 1 - short / long side of its box)
+        c0 = out['counts_host']
+        bx = torch.cat([out['boxes'][i, :c0[i]] for i in range(len(images))]).to(torch.long).float()
+        bw, bh = (bx[:, 2] - bx[:, 0]).clamp(min=1), (bx[:, 3] - bx[:, 1]).clamp(min=1)
+        roofline['crop_shapes'] = {'short_over_long_mean': round(float((torch.minimum(bw, bh) / torch.maximum(bw, bh)).mean()), 4),
+                                   'wide_fraction': round(float((bw > bh).float().mean()), 4)}
         if not args.no_clocks:
             # the clock and the power the card delivers while it runs this step (and, for comparison, its bare MFMA loop)
             with ClockSampler(dev) as cs:
@@ -434,7 +482,8 @@ def run_pipeline(args, rank, local_rank, world, dev):
         # (taken BEFORE the CPU-heavy legs: the oracle's OpenMP threads keep spinning for a while and slow the launch path)
         w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False)
         workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
-                     'match_stress_configs3': match_stress_cases(dev, 200, 3)}
+                     'match_stress_configs3': match_stress_cases(dev, 200, 3),
+                     'embed_planted_boxes': embed_planted_boxes(dev, enc, images[0], ipg * dpi)}
 
     peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
     if roofline is not None and peaks is not None:
@@ -476,11 +525,50 @@ def run_pipeline(args, rank, local_rank, world, dev):
     }
     if h2d is not None:
         line.update(h2d)
-    for key, val in (('roofline', roofline), ('measured_peaks', peaks), ('parity', parity), ('cpu_baseline', cpu), ('workloads', workloads),
-                     ('verify', verify)):
+    for key, val in (('value_by_detector_precision', by_precision), ('roofline', roofline), ('measured_peaks', peaks), ('parity', parity),
+                     ('cpu_baseline', cpu), ('workloads', workloads), ('verify', verify)):
         if val is not None:
             line[key] = val
     return line
+
+
+def embed_planted_boxes(dev, enc, image, n_boxes, seed=7, reps=5):
+    """The embed stage on PLANTED proposals with a realistic spread of shapes (uniform boxes of 60-250 px on the
+    2048^2 canvas, seed 7; width and height independent) instead of the random-weight detector's boxes, which all have one
+    shape: how much of the constant-padding skipping survives a spread of aspect ratios.  Crops + extents once, then the
+    embedder alone, with and without the work lists."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import classification as C
+    g = torch.Generator().manual_seed(seed)
+    H, W = image.shape[1:]
+    wh = 60 + 190 * torch.rand(n_boxes, 2, generator=g)
+    xy = torch.rand(n_boxes, 2, generator=g) * (torch.tensor([W, H], dtype=torch.float32) - wh)
+    boxes = torch.cat((xy, xy + wh), dim=1).to(dev)
+    eng = enc.engine()
+    crops = ops.crop_resize(image, boxes, 256, mode=2, mean=enc.input_mean, std=enc.input_std)
+    ext = ops.crop_extents(boxes, None, H, W, 256)
+    const = eng.const_crop(enc.input_mean, enc.input_std, 4, 256)
+
+    def timed(**kw):
+        eng.embed_packed(crops, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            eng.embed_packed(crops, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_on, ms_off = timed(ext=ext, const_in=const), timed()
+    ops.PROFILE = ops.ConvProfile()
+    eng.embed_packed(crops, ext=ext, const_in=const)
+    summ = ops.PROFILE.summary()
+    ops.PROFILE = None
+    alg, exe = sum(v['flops'] for v in summ.values()), sum(v['flops_executed'] for v in summ.values())
+    b = boxes.to(torch.long).float().cpu()
+    bw, bh = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    return {'boxes': n_boxes, 'box_px': '60-250 x 60-250 uniform, independent sides', 'short_over_long_mean': round(float((torch.minimum(bw, bh) / torch.maximum(bw, bh)).mean()), 4),
+            'embed_ms_with_skipping': round(ms_on, 3), 'embed_ms_without': round(ms_off, 3), 'speedup': round(ms_off / ms_on, 4),
+            'executed_over_algorithmic_flops': round(exe / alg, 4), 'executed_tflops': round(exe / ms_on / 1e9, 1)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -614,6 +702,12 @@ def run_match_stress(args, rank, local_rank, world, dev):
                          'avg_launch_us': head['us_per_launch'], 'cases': cases}}
 
 
+def host_threads_for(world, cores):
+    """Host threads one rank may use: its share of the node's cores (image synthesis, pinned staging and the oracle legs use torch's
+    intra-op pool; N ranks on one node must not each claim every core)."""
+    return max(1, cores // max(1, world))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -622,6 +716,8 @@ def main():
     rank, local_rank, world = cdist.init()
     if world != args.gpus and world > 1:
         args.gpus = world
+    if world > 1:
+        torch.set_num_threads(host_threads_for(world, os.cpu_count() or 1))
     dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
     torch.cuda.set_device(dev)
     line = {'pipeline': run_pipeline, 'detector': run_detector, 'match-stress': run_match_stress}[args.workload](args, rank, local_rank, world, dev)

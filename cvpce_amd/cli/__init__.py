@@ -27,6 +27,9 @@ _DIR = dict(exists=True, file_okay=False, dir_okay=True, readable=True)
 _FILE = dict(exists=True, file_okay=True, dir_okay=False, readable=True)
 
 
+EVAL_WINDOW = 8     # images read ahead and run through the kernels together by the evaluation commands
+
+
 def _coco_or(thresholds, coco):
     return [f.item() for f in torch.linspace(.5, .95, 10)] if coco else list(thresholds)
 
@@ -239,17 +242,21 @@ def eval_planograms(img_dir, test_imgs, test_annotations, planograms, datatype, 
     classifier = production.Classifier(_load_encoder(dihe_state), sampleset, batch_size=8, load=load_classifier_index)
     evaluator = production.PlanogramEvaluator(generator, classifier, production.PlanogramComparator())
     total_a = total_e = 0.0
-    for i in range(len(planoset)):
-        datum = planoset[i]
-        img, plano = (datum[0], datum[3]) if datatype == 'gp' else datum
-        acc = float(evaluator.evaluate(img, plano))
-        err = acc - plano['actual_accuracy']
-        if verbose:
-            print(f'Detected accuracy: {acc:.3f}, Actual accuracy: {plano["actual_accuracy"]:.3f}, Error: {err:.3f}, SE: {err ** 2:.3f}')
-        elif i % 10 == 0:
-            print(i)
-        total_e += err ** 2
-        total_a += acc
+    # the reference evaluates one image at a time (cvpce/cli/eval.py:224-230); here EVAL_WINDOW images are read ahead and detected /
+    # embedded / matched together (PlanogramEvaluator.evaluate_batch: same per-image results, one pass of the kernels per window)
+    for s in range(0, len(planoset), EVAL_WINDOW):
+        data = [planoset[i] for i in range(s, min(s + EVAL_WINDOW, len(planoset)))]
+        pairs = [((d[0], d[3]) if datatype == 'gp' else d) for d in data]
+        accs = evaluator.evaluate_batch([img for img, _ in pairs], [plano for _, plano in pairs])
+        for i, ((img, plano), acc) in enumerate(zip(pairs, accs), start=s):
+            acc = float(acc)
+            err = acc - plano['actual_accuracy']
+            if verbose:
+                print(f'Detected accuracy: {acc:.3f}, Actual accuracy: {plano["actual_accuracy"]:.3f}, Error: {err:.3f}, SE: {err ** 2:.3f}')
+            elif i % 10 == 0:
+                print(i)
+            total_e += err ** 2
+            total_a += acc
     print(f'--> Mean accuracy {total_a / len(planoset)}')
     print(f'--> MSE: {total_e / len(planoset)}')
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     const int npp = (wc == 0) ? 6 : 5;
     auto issue_patch = [&](int n, int ty, int tx, int c, int buf, int ext) {
         const int y0 = ty * G2_T - 1, x0 = tx * G2_T - 1;
-        const int ey = ext >> 16, ex = ext & 0xFFFF;
+        const int ey = (ext >> 12) & 0xFFF, ex = ext & 0xFFF;
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the volatile
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
@@ -304,20 +304,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         if (!(CVPCE_DBG & 64)) __builtin_amdgcn_s_barrier();                                                   \
         issue_next_patch();                                                                                    \
     }
+    // LIST launches: a tile computes only its first `rows_` (4 | 8 | 12 | 16) output rows -- the rest lies in the crop's constant
+    // region and is never read by anyone.  Output row r needs patch rows r .. r + 2, so a step streams patch rows 0 .. rows_ + 1
+    // and stops (three uniform branches per step); the two reads it has prefetched beyond are stale and land, in order, before
+    // the next step's rows 0 and 1 that follow them into the same ring slots.  Accumulator rows rows_, rows_ + 1 collect partial
+    // sums nobody stores.  BEFORE / AFTER: what precedes the step's hand-over to the next one (the chunk hand-off in the last step).
+#define G2_ROWS_AND_TAIL(T, TN, BUFB_NEXT, BEFORE)                                                             \
+    G2_RP(T, 0) G2_RP(T, 1) G2_RP(T, 2) G2_RP(T, 3) G2_RP(T, 4) G2_RP(T, 5)                                    \
+    if (!LIST || rows_ > 4) { G2_RP(T, 6) G2_RP(T, 7) G2_RP(T, 8) G2_RP(T, 9) }                                \
+    if (!LIST || rows_ > 8) { G2_RP(T, 10) G2_RP(T, 11) G2_RP(T, 12) G2_RP(T, 13) }                            \
+    if (!LIST || rows_ > 12) {                                                                                 \
+        G2_RP(T, 14) G2_RP(T, 15)                                                                              \
+        BEFORE                                                                                                 \
+        G2_SET_E(TN, BUFB_NEXT)                                                                                \
+        G2_READ(TN, 0) G2_ROW(T, 16)                                                                           \
+        G2_READ(TN, 1) G2_ROW(T, 17)                                                                           \
+    } else {                                                                                                   \
+        BEFORE                                                                                                 \
+        G2_SET_E(TN, BUFB_NEXT)                                                                                \
+        G2_READ(TN, 0)                                                                                         \
+        G2_READ(TN, 1)                                                                                         \
+    }
     // step T < 5: fetch the next step's weights, stream the rows; rows 16, 17 prefetch rows 0, 1 of step T + 1
 #define G2_STEP(T)                                                                                             \
     {                                                                                                          \
         G2_LOAD_A((T) + 1, sb_cur)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        G2_ROWS_0_15(T)                                                                                        \
-        G2_SET_E((T) + 1, bufb)                                                                                \
-        G2_READ((T) + 1, 0) G2_ROW(T, 16)                                                                      \
-        G2_READ((T) + 1, 1) G2_ROW(T, 17)                                                                      \
+        G2_ROWS_AND_TAIL(T, (T) + 1, bufb, )                                                                   \
     }
 
     // ---- prologue ----
     int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct, t_ext_;
     tile_of(0, t_n, t_ty, t_tx, t_ct, t_ext_);
+    int rows_ = LIST ? ((t_ext_ >> 24) & 0xFF) : NB;     // output rows of the current tile that are computed (LIST: 4 | 8 | 12 | 16)
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
@@ -358,15 +377,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         {
             G2_LOAD_A(0, sb_next)        // step 0 of the next chunk (slot 0); past the last chunk a harmless reload
             __builtin_amdgcn_sched_barrier(0);
-            G2_ROWS_0_15(5)
             // After the last chunk the barrier, the reads and the weight loads still run -- on valid, unused data -- so
             // that the loop body has one shape and the accumulators stay in place.
             const int nbufi = (bufi == 2) ? 0 : bufi + 1;
             const unsigned nbufb = lds_a + (unsigned)nbufi * G2_A_BYTES;
-            G2_HANDOFF()                                 // chunk cc + 2 -> the buffer chunk cc - 1 used
-            G2_SET_E(0, nbufb)
-            G2_READ(0, 0) G2_ROW(5, 16)
-            G2_READ(0, 1) G2_ROW(5, 17)
+            G2_ROWS_AND_TAIL(5, 0, nbufb, G2_HANDOFF())  // hand-off: chunk cc + 2 -> the buffer chunk cc - 1 used
             bufb = nbufb;
             bufi = nbufi;
         }
@@ -375,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         if (cchunk + 1 == nchunks) {
             // ---- epilogue of this tile (the next tile's patch, weights and first rows are already in flight) ----
             const int n = t_n, ty = t_ty, tx = t_tx, ct = t_ct;
+            const int rows_t = rows_;            // (LIST) rows of this tile that were computed: the others are not stored
             f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
             load_bias(n_ct, nbias);
             const int col = g2_col(lp);
@@ -444,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                                 r[4 * mt + j] = fmaxf(v, fmaxf(up, dn));
                             }
                         }
-                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
+                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!LIST || 2 * i < rows_t) && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[0], r[1], r[2], r[3]}));
                         const uint2 h2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 for (int nt = 0; nt < NB; ++nt) {
                     const int oy = ty * G2_T + nt;
                     const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
-                    const bool store_lane = oy < a.H && ox < a.W;     // ragged right / bottom tiles
+                    const bool store_lane = oy < a.H && ox < a.W && (!LIST || nt < rows_t);     // ragged right / bottom tiles; (LIST) computed rows only
                     bool keep = true;                // masked-out pixels (gaps of a level atlas) are stored as zeros
                     if (a.mask) keep = ((lrow[seq * 16 + nt] >> col) & 1u) != 0;
                     f32x4 r0 = acc[0][nt], r1 = acc[1][nt];
@@ -476,7 +492,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 for (int nt = 0; nt < NB; ++nt) acc[mt][nt] = nbias[mt];
             cchunk = 0;
             ++seq;
-            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
+            if (seq < my_tiles) {
+                tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
+                if constexpr (LIST) rows_ = (t_ext_ >> 24) & 0xFF;
+            }
         } else {
             ++cchunk;
         }
@@ -548,6 +567,25 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (gmax) return fuse_pool2 ? launch_halo2<E, true, true>(a, s) : launch_halo2<E, false, true>(a, s);
+    if (mask) {
+        // a masked launch keeps every workgroup's tile list in LDS (G2_MAX_SEQ entries): a batch too large for that is split
+        // into launches over whole images (the tile sequence restarts with every image, so the results do not change)
+        const long long per_image = (long long)a.tiles_per_image * ((Cout + 255) / 256);
+        const long long cap = (long long)G2_MAX_SEQ * g_cvpce_persistent_wgs;
+        if (per_image > cap) return CVPCE_ERR_ARG;
+        const int n_per = (int)(cap / per_image);
+        for (int n0 = 0; n0 < N; n0 += n_per) {
+            Halo2Args b = a;
+            b.N = (N - n0) < n_per ? (N - n0) : n_per;
+            b.in = a.in + (size_t)n0 * H * W * Cin;
+            b.out = a.out + (size_t)n0 * H * W * Cout;
+            b.ptiles = b.N * a.tiles_per_image;
+            b.in_bytes = (unsigned)((long long)b.N * H * W * Cin * 2);
+            const int rc = launch_halo2<E, false, false>(b, s);
+            if (rc != CVPCE_OK) return rc;
+        }
+        return CVPCE_OK;
+    }
     return fuse_pool2 ? launch_halo2<E, true, false>(a, s) : launch_halo2<E, false, false>(a, s);
 }
 

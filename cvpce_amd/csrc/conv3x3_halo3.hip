@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     const int npp = (wid < 7) ? 5 : 4;
     auto issue_patch = [&](int n, int ty, int tx, int c32, int buf, int ext) {
         const int y0 = ty * G3_TH - 1, x0 = tx * G3_TW - 1;
-        const int ey = ext >> 16, ex = ext & 0xFFFF;
+        const int ey = (ext >> 12) & 0xFFF, ex = ext & 0xFFF;
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the empty
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
@@ -249,14 +249,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         { G3_TIC() __builtin_amdgcn_s_barrier(); G3_TOC(2) }                                                   \
         issue_next_patch();                                                                                    \
     }
+    // LIST launches compute only the first `rows_` (4 | 8 | 12 | 16) output rows of a tile: see G2_ROWS_AND_TAIL in conv3x3_halo2.hip
+#define G3_ROWS_AND_TAIL(T, TN, BUFB_NEXT, BEFORE)                                                             \
+    G3_RP(T, 0) G3_RP(T, 1) G3_RP(T, 2) G3_RP(T, 3) G3_RP(T, 4) G3_RP(T, 5)                                    \
+    if (!LIST || rows_ > 4) { G3_RP(T, 6) G3_RP(T, 7) G3_RP(T, 8) G3_RP(T, 9) }                                \
+    if (!LIST || rows_ > 8) { G3_RP(T, 10) G3_RP(T, 11) G3_RP(T, 12) G3_RP(T, 13) }                            \
+    if (!LIST || rows_ > 12) {                                                                                 \
+        G3_RP(T, 14) G3_RP(T, 15)                                                                              \
+        BEFORE                                                                                                 \
+        G3_SET_E(TN, BUFB_NEXT)                                                                                \
+        G3_READ(TN, 0) G3_ROW(T, 16)                                                                           \
+        G3_READ(TN, 1) G3_ROW(T, 17)                                                                           \
+    } else {                                                                                                   \
+        BEFORE                                                                                                 \
+        G3_SET_E(TN, BUFB_NEXT)                                                                                \
+        G3_READ(TN, 0)                                                                                         \
+        G3_READ(TN, 1)                                                                                         \
+    }
 #define G3_STEP(T)                                                                                             \
     {                                                                                                          \
         G3_LOAD_A((T) + 1, sb_cur)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        G3_ROWS_0_15(T)                                                                                        \
-        G3_SET_E((T) + 1, bufb)                                                                                \
-        G3_READ((T) + 1, 0) G3_ROW(T, 16)                                                                      \
-        G3_READ((T) + 1, 1) G3_ROW(T, 17)                                                                      \
+        G3_ROWS_AND_TAIL(T, (T) + 1, bufb, )                                                                   \
         G3_STAMP_STEP()                                                                                        \
     }
     // last step of a sub-chunk (T = 2 or 5) with the hand-off.  After the last sub-chunk the barrier, the reads and the
@@ -265,13 +279,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     {                                                                                                          \
         G3_LOAD_A(TN, SBN)                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        G3_ROWS_0_15(T)                                                                                        \
         const int nbufi = (bufi == 2) ? 0 : bufi + 1;                                                          \
         const unsigned nbufb = lds_a + (unsigned)nbufi * G3_A_BYTES;                                           \
-        G3_HANDOFF()                                                                                           \
-        G3_SET_E(TN, nbufb)                                                                                    \
-        G3_READ(TN, 0) G3_ROW(T, 16)                                                                           \
-        G3_READ(TN, 1) G3_ROW(T, 17)                                                                           \
+        G3_ROWS_AND_TAIL(T, TN, nbufb, G3_HANDOFF())                                                           \
         bufb = nbufb;                                                                                          \
         bufi = nbufi;                                                                                          \
     }
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // ---- prologue ----
     int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct, t_ext_;
     tile_of(0, t_n, t_ty, t_tx, t_ct, t_ext_);
+    int rows_ = LIST ? ((t_ext_ >> 24) & 0xFF) : NB;     // output rows of the current tile that are computed (LIST: 4 | 8 | 12 | 16)
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
@@ -314,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         if (cchunk + 1 == nchunks) {
             // ---- epilogue of this tile (the next tile's patch, weights and first fragments are already in flight) ----
             const int n = t_n, ty = t_ty, tx = t_tx, ct = t_ct;
+            const int rows_t = rows_;            // (LIST) rows of this tile that were computed: the others are not stored
             G3_TIC()
             f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
             load_bias(n_ct, nbias);
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                                 r[4 * mt + j] = fmaxf(v, fmaxf(up, dn));
                             }
                         }
-                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
+                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!LIST || 2 * i < rows_t) && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[0], r[1], r[2], r[3]}));
                         const uint2 h2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                 for (int nt = 0; nt < NB; ++nt) {
                     const int oy = ty * G3_TH + nt;
                     const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
-                    const bool store_lane = oy < a.H && ox < a.W;     // ragged right / bottom tiles
+                    const bool store_lane = oy < a.H && ox < a.W && (!LIST || nt < rows_t);     // ragged right / bottom tiles; (LIST) computed rows only
                     const int co = ct * TC + wc * 32 + 8 * lq;        // this lane's 8 consecutive couts
                     f32x4 r0 = acc[0][nt], r1 = acc[1][nt];
                     if (a.relu) {
@@ -378,7 +390,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
             G3_TOC(3)
             cchunk = 0;
             ++seq;
-            if (seq < my_tiles) tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
+            if (seq < my_tiles) {
+                tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
+                if constexpr (LIST) rows_ = (t_ext_ >> 24) & 0xFF;
+            }
         } else {
             ++cchunk;
         }

@@ -13,7 +13,9 @@
 // by a pool: an upper bound of the true extent, the same formula on the producer's and the consumer's side of a tensor).
 //
 // This kernel turns the extents into one compacted, crop-major tile list per layer (device-resident counts: no host sync):
-//   entry = ((ey_in << 16 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
+//   entry = ((rows << 24 | ey_in << 12 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
+// rows = how many of the tile's 16 conv-output rows (before a fused pool) are NOT wholly constant, rounded up to 4: the halo
+// kernels stop streaming patch rows behind them (rows of a tile below the crop's content extent are never read by anyone).
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 
@@ -45,13 +47,14 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
     __syncthreads();
     for (int n0 = 0; n0 < a.n; n0 += 1024) {
         const int n = n0 + tid;
-        int ny = 0, nx = 0, eiy = 0, eix = 0;
+        int ny = 0, nx = 0, eiy = 0, eix = 0, eoy_ = 0;
         if (n < a.n) {
             const bool is_const = n == a.n - 1;
             const int ey0 = is_const ? a.S : a.ext0[2 * n], ex0 = is_const ? a.S : a.ext0[2 * n + 1];
             ny = tiles_y; nx = tiles_x;
             if (L.skip) {
                 const int eoy = skl_extent(ey0, a.S, L.out_shift, L.out_grow, L.H), eox = skl_extent(ex0, a.S, L.out_shift, L.out_grow, L.W);
+                eoy_ = eoy;
                 const int cy = (eoy + L.tile_h - 1) / L.tile_h, cx = (eox + L.tile_w - 1) / L.tile_w;   // tile row ty is computed iff ty * tile_h < eoy
                 ny = cy < tiles_y ? cy : tiles_y;
                 nx = cx < tiles_x ? cx : tiles_x;
@@ -75,10 +78,19 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
         if (tid == 0) s_base += chunk_total;
         // entries of this thread's crop; blockIdx.y splits the crops among workgroups (every workgroup runs the same scan)
         if (n < a.n && (n % (int)gridDim.y) == (int)blockIdx.y) {
-            const unsigned long long hi = ((unsigned long long)(((unsigned)eiy << 16) | (unsigned)eix)) << 32;
+            const unsigned ext = ((unsigned)eiy << 12) | (unsigned)eix;
             for (int j = 0; j < cnt; ++j) {
                 const int ty = j / nx, tx = j - ty * nx;
-                list[base + j] = hi | (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
+                // active conv-output rows of this tile, in sixteenths of the tile height, rounded up to a multiple of 4
+                int rows = 16;
+                if (L.skip) {
+                    const int left = eoy_ - ty * L.tile_h;
+                    const int act = left < L.tile_h ? left : L.tile_h;
+                    rows = ((act * 16 + L.tile_h - 1) / L.tile_h + 3) & ~3;
+                    if (rows > 16) rows = 16;
+                }
+                list[base + j] = ((unsigned long long)(((unsigned)rows << 24) | ext) << 32) |
+                                 (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
             }
         }
         __syncthreads();
@@ -95,7 +107,7 @@ extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, const
     a.ext0 = ext0; a.n = n_images; a.S = S; a.nl = n_layers; a.lists = lists; a.stride = list_stride; a.counts = counts;
     for (int i = 0; i < n_layers; ++i) {
         const cvpce_skip_layer& l = layers[i];
-        if (l.H <= 0 || l.W <= 0 || l.tile_h <= 0 || l.tile_w <= 0 || l.in_H <= 0 || l.in_W <= 0 || l.in_H > 65535 || l.in_W > 65535) return CVPCE_ERR_ARG;
+        if (l.H <= 0 || l.W <= 0 || l.tile_h <= 0 || l.tile_w <= 0 || l.in_H <= 0 || l.in_W <= 0 || l.in_H > 4095 || l.in_W > 4095) return CVPCE_ERR_ARG;
         if (l.in_shift < 0 || l.out_shift < 0 || l.in_shift > 15 || l.out_shift > 15 || l.in_grow < 0 || l.out_grow < 0) return CVPCE_ERR_ARG;
         const long long ty = (l.H + l.tile_h - 1) / l.tile_h, tx = (l.W + l.tile_w - 1) / l.tile_w;
         if (ty > 255 || tx > 255 || ty * tx * n_images > list_stride) return CVPCE_ERR_ARG;

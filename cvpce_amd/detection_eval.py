@@ -18,15 +18,26 @@ def evaluate_detections(p_model, c_model, testset, trainset, thresholds=(0.5,), 
     targets = {c: [] for c in range(n_cls)}
     confidences = {c: [] for c in range(n_cls)}
     all_p, all_t, all_c = [], [], []
+    # detect -> crop -> embed -> match of a whole proposal batch in one pass of the kernels (the reference crops and classifies image
+    # by image, detection_eval.py:27-30); confidence threshold -1: every kept detection is embedded, as in the reference
+    pipe = production.BatchedPipeline(p_model, classifier, confidence_threshold=-1.0) if hasattr(p_model, 'engine') else None
     for i, batch in enumerate(_batches(testset, proposal_batch_size)):
         if verbose and i % 10 == 0:
             print(f'{i}...')
-        images = [img.cuda(non_blocking=True) for img, _ in batch]
-        for img, r, (_, t) in zip(images, p_model(images), batch):
+        images = [img.cuda(non_blocking=True).to(torch.float32).contiguous() for img, _ in batch]
+        if pipe is not None:
+            out = pipe.run(images)
+            ob, osc, oix = out['boxes'].cpu(), out['scores'].cpu(), out['indices'][:, :, 0].cpu()
+            results = [{'boxes': ob[j, :c], 'scores': osc[j, :c], 'idx': oix[j, :c]} for j, c in enumerate(out['counts_host'])]
+        else:
+            results = p_model(images)
+        for img, r, (_, t) in zip(images, results, batch):
             boxes = r['boxes']
             keep = production._nondegenerate(boxes) if len(boxes) else torch.zeros(0, dtype=torch.bool, device=boxes.device)
             boxes, scores = boxes[keep], r['scores'][keep]
-            if len(boxes):
+            if 'idx' in r:
+                classes = [[classifier.annotations[k]] for k in r['idx'][keep].tolist()]
+            elif len(boxes):
                 crops = ops.crop_resize(img.contiguous(), boxes, datautils.CLASSIFICATION_IMAGE_SIZE, mode=0)
                 classes = classifier.classify(crops)
             else:

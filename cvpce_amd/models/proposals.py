@@ -336,7 +336,7 @@ class GLNEngine:
                 if ds is None and ops.can_fuse_bottleneck(x, c1, c2, c3, x):
                     x = ops.bottleneck(x, c1, c2, c3, x)           # identity block: one launch, intermediates in LDS
                     continue
-                if ds is not None and ops.can_fuse_bottleneck(x, c1, c2, c3, x.new_empty((x.shape[0], x.shape[1], x.shape[2], c3.cout))):
+                if ds is not None and ops.can_fuse_bottleneck(x, c1, c2, c3, (x.shape[0], x.shape[1], x.shape[2], c3.cout)):
                     x = ops.bottleneck(x, c1, c2, c3, ops.conv2d(x, ds))   # layer1's first block (stride 1): shortcut conv, then one launch
                     continue
                 identity, joined = self._beside(2, lambda: ops.conv2d(x, ds)) if ds is not None else (x, None)
@@ -558,6 +558,10 @@ class GLNEngine:
             entry['replays'] += 1
             self.transform(images, out=entry['static_in'])
             entry['graph'].replay()
+            # a graph that earns its keep lowers the capture threshold again (it is only ever raised when graphs are evicted barely
+            # used: one burst of mixed geometries must not leave a later, stable geometry waiting 16 calls for its capture)
+            if entry['replays'] == 4 and self.__dict__.get('_capture_on_sight', CAPTURE_ON_SIGHT) > CAPTURE_ON_SIGHT:
+                self._capture_on_sight = max(CAPTURE_ON_SIGHT, self._capture_on_sight // 2)
             # results leave the graph's private memory: a later replay must not overwrite what the caller still holds
             return ops.clone_views(entry['static_out'])
         sights = self.__dict__.setdefault('_sights', OrderedDict())

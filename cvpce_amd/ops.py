@@ -191,9 +191,12 @@ FUSED_BOTTLENECK_MAX_PLANES = int(_os.environ.get('CVPCE_FUSED_BOTTLENECK_MAXP',
 
 
 def can_fuse_bottleneck(x, c1, c2, c3, residual):
-    """cvpce_bottleneck_fused covers: 1x1 (s1) -> 3x3 (s1, p1) -> 1x1 (s1), planes P in {64, 128, 256}, 4P outputs, a same-size residual."""
+    """cvpce_bottleneck_fused covers: 1x1 (s1) -> 3x3 (s1, p1) -> 1x1 (s1), planes P in {64, 128, 256}, 4P outputs, a same-size residual.
+    `residual`: the tensor, or just its shape (a caller deciding BEFORE it computes the projection shortcut)."""
     p = c1.cout
     n, h, w, cin = x.shape
+    if residual is not None and not torch.is_tensor(residual):
+        residual = torch.empty(tuple(residual), device='meta')
     return (USE_FUSED_BOTTLENECK and not FORCE_GENERIC_CONV and p in (64, 128, 256) and p <= FUSED_BOTTLENECK_MAX_PLANES and cin % 64 == 0 and c1.cin_pad == cin
             and (c1.kh, c1.stride, c1.pad) == (1, 1, 0) and (c2.kh, c2.kw, c2.stride, c2.pad) == (3, 3, 1, 1) and c2.cin == p and c2.cout == p
             and (c3.kh, c3.stride, c3.pad) == (1, 1, 0) and c3.cin == p and c3.cout == 4 * p and c2.k_pad == 9 * p

@@ -265,6 +265,42 @@ class PlanogramEvaluator:
         return self.planogram_comparator.compare(planogram, {'boxes': boxes.detach().cpu(), 'labels': classes},
                                                  image, self.classifier)
 
+    def detect_and_classify_batch(self, images):
+        """[(boxes (P,4) cpu, labels list[str])] for a list of images -- what `evaluate` hands to the comparator, per image, but
+        computed for the whole list at once: images of one size go through `BatchedPipeline` together (one detector pass, one
+        embedder schedule, one distance GEMM).  Per-image results are the ones `evaluate` gets: neither the detector's nor the
+        embedder's result for an image depends on what it is batched with (tests/test_gpu_harness.py), images of different
+        sizes are never mixed in a batch (the padded batch shape enters the anchors, like in torchvision), and the zero-area
+        boxes `generate_proposals_and_images` drops are dropped here too."""
+        pg = self.proposal_generator
+        pipe = self.__dict__.get('_pipe')
+        if pipe is None or pipe.detector is not pg.detector or pipe.classifier is not self.classifier:
+            pipe = self._pipe = BatchedPipeline(pg.detector, self.classifier, pg.condfidence_threshold)
+        pipe.confidence_threshold = pg.condfidence_threshold
+        out = [None] * len(images)
+        groups = {}
+        for i, img in enumerate(images):
+            groups.setdefault(tuple(img.shape), []).append(i)
+        for idxs in groups.values():
+            res = pipe.run([images[i].to(device=pg.device, dtype=torch.float32).contiguous() for i in idxs])
+            boxes, indices = res['boxes'].cpu(), res['indices'][:, :, 0].cpu()
+            for j, i in enumerate(idxs):
+                c = res['counts_host'][j]
+                b, ix = boxes[j, :c], indices[j, :c]
+                if c:
+                    ok = _nondegenerate(b)
+                    b, ix = b[ok], ix[ok]
+                out[i] = (b, [self.classifier.annotations[k] for k in ix.tolist()])
+        return out
+
+    def evaluate_batch(self, images, planograms):
+        """[evaluate(image, planogram) for image, planogram in zip(...)] with the detect / crop / embed / match half batched
+        (`detect_and_classify_batch`); the comparator (CPU graph matching, RANSAC, re-classification of missing positions) runs
+        per image as in production.py:123-129."""
+        dets = self.detect_and_classify_batch(images)
+        return [self.planogram_comparator.compare(plano, {'boxes': b, 'labels': labels}, img, self.classifier)
+                for img, plano, (b, labels) in zip(images, planograms, dets)]
+
 
 class BatchedPipeline:
     """detect -> RoI crop -> embed -> match for a batch of shelf images, device-resident end to end.

@@ -184,7 +184,9 @@ typedef struct {
 } cvpce_skip_layer;
 /* ext0 [n_images - 1][2] (cvpce_crop_extents; the constant crop, image n_images - 1, is implied), layers [host] ->
  * lists[l * list_stride + i] for i < counts[l] (device): the tiles layer l computes, crop-major,
- *   entry = ((ey_in << 16 | ex_in) << 32) | (n << 16) | (ty << 8) | tx       (ey_in / ex_in: the INPUT tensor's extents of crop n)
+ *   entry = ((rows << 24 | ey_in << 12 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
+ * (ey_in / ex_in < 4096: the INPUT tensor's extents of crop n; rows in {4, 8, 12, 16}: the tile's conv-output rows that are not
+ * wholly constant, rounded up to 4 -- the halo kernels compute only those, the rest of the tile is neither computed nor stored)
  * list_stride >= n_images * tiles of the largest layer.  No host synchronisation: the kernels read counts[l] themselves. */
 int cvpce_embed_worklists(const int* ext0, int n_images, int S, const cvpce_skip_layer* layers, int n_layers,
                           unsigned long long* lists, long long list_stride, int* counts, void* stream);

@@ -38,10 +38,14 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-FIT_KEYS = ('head.classification_head.conv.4', 'head.classification_head.conv.6', 'head.classification_head.cls_logits',
-            'head.regression_head.conv.4', 'head.regression_head.conv.6', 'head.regression_head.bbox_reg')
-FROZEN_TOWER = (0, 2)       # tower convs evaluated once per scene (cached)
-FIT_TOWER = (4, 6)
+TOWER = (0, 2, 4, 6)
+FROZEN_TOWER = ()           # tower convs evaluated once per scene (cached); set by --fit-from
+FIT_TOWER = TOWER
+
+
+def fit_keys():
+    return tuple(f'head.{h}.conv.{i}' for h in ('classification_head', 'regression_head') for i in FIT_TOWER) + \
+        ('head.classification_head.cls_logits', 'head.regression_head.bbox_reg')
 
 
 def box_iou(a, b):
@@ -121,14 +125,21 @@ def main():
     ap.add_argument('--epochs', type=int, default=30)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--eval-images', type=int, default=6)
+    ap.add_argument('--fit-from', type=int, default=0, choices=[0, 2, 4, 6], help='first tower conv that is fitted (earlier ones stay at the seeded init)')
+    ap.add_argument('--residual-gain', type=float, default=0.25,
+                    help='synthetic_gln residual_gain of the frozen base (1.0 = plain random init: its FPN levels differ 15x in scale and P3 carries '
+                         'no fine detail -- nothing fits on it; 0.25 = the damped, trained-like conditioning of cvpce_amd.synthetic)')
     ap.add_argument('--out', default=os.path.join(HERE, 'fitted_head.pt'))
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
+    global FROZEN_TOWER, FIT_TOWER
+    FROZEN_TOWER, FIT_TOWER = tuple(i for i in TOWER if i < a.fit_from), tuple(i for i in TOWER if i >= a.fit_from)
+    FIT_KEYS = fit_keys()
     from cvpce_amd import synthetic, metrics
     from oracle import gln as og
 
     t0 = time.perf_counter()
-    det = synthetic.synthetic_gln(seed=0, detections_per_img=200)
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=200, residual_gain=a.residual_gain)
     sd = {k: v.clone() for k, v in det.state_dict().items()}
     products = synthetic.product_images(1024, seed=200)          # = the first 1024 of tests/accuracy.py's product set
     print(f'[fit] model + products ({time.perf_counter() - t0:.1f} s)', flush=True)
@@ -147,8 +158,21 @@ def main():
 
     g = torch.Generator().manual_seed(4242)
     params = {}
+    # the frozen features have the scale the random backbone gives them (FPN rms 0.05-0.15 with the damped base): the first fitted
+    # conv of each tower starts at He scale TIMES 1 / rms of its input, the later tower convs at He scale, the output convs at
+    # torchvision's std 0.01 -- activations of order one from the first step on
+    rms = {}
+    for ti, prefix in enumerate(('head.classification_head', 'head.regression_head')):
+        sq = sum(float(t.pow(2).sum()) for sc in scenes for t in sc[0][ti]); cnt = sum(t.numel() for sc in scenes for t in sc[0][ti])
+        rms[prefix] = math.sqrt(sq / cnt)
+    print(f'[fit] tower input rms {rms}', flush=True)
     for key in FIT_KEYS:
-        w = torch.empty_like(sd[key + '.weight']).normal_(0, 0.01, generator=g)
+        std = 0.01
+        if '.conv.' in key:
+            std = math.sqrt(2.0 / (256 * 9))
+            if key.endswith(f'.conv.{FIT_TOWER[0]}'):
+                std /= rms[key.rsplit('.conv.', 1)[0]]
+        w = torch.empty_like(sd[key + '.weight']).normal_(0, std, generator=g)
         b = torch.zeros_like(sd[key + '.bias'])
         if key.endswith('cls_logits'):
             b.fill_(-math.log((1 - 0.01) / 0.01))                # torchvision's prior-probability bias
@@ -169,7 +193,7 @@ def main():
             opt.zero_grad(set_to_none=True)
             (loss_c + loss_r).backward()
             opt.step(); sched.step()
-            tot_c += float(loss_c); tot_r += float(loss_r)
+            tot_c += float(loss_c.detach()); tot_r += float(loss_r.detach())
         print(f'[fit] epoch {ep}: focal {tot_c / len(scenes):.4f}  l1 {tot_r / len(scenes):.4f}  ({time.perf_counter() - t0:.1f} s)', flush=True)
 
     fitted = {k: v.detach().clone() for k, v in params.items()}
@@ -187,7 +211,7 @@ def main():
                      'confident_per_image': nconf, 'products_per_image': [len(t) for t in tg]}
         print(f'[fit] oracle on {a.eval_images} evaluation scenes of {size}^2: {rep[size]}', flush=True)
     torch.save({'tensors': fitted,
-                'recipe': {'script': 'tests/golden/fit_head.py', 'scenes': a.scenes, 'epochs': a.epochs, 'lr': a.lr, 'base': 'synthetic_gln(seed=0)',
+                'recipe': {'script': 'tests/golden/fit_head.py', 'scenes': a.scenes, 'epochs': a.epochs, 'lr': a.lr, 'base': f'synthetic_gln(seed=0, residual_gain={a.residual_gain})', 'residual_gain': a.residual_gain, 'fit_from': a.fit_from,
                            'fit_keys': list(FIT_KEYS), 'oracle_eval': rep}}, a.out)
     print(f'[fit] wrote {a.out} ({os.path.getsize(a.out) / 1e6:.1f} MB, {time.perf_counter() - t0:.0f} s)', flush=True)
 

@@ -34,8 +34,12 @@ def _worker(rank, world, port, n_gallery, n_images, q):
     mine = cdist.shard_images(n_images, rank, world)
     t = cdist.max_over_ranks(float(rank + 1), torch.device('cpu'))
     cdist.barrier()
-    q.put((rank, full, mine, t))
+    # the optional final gather of bench.py --verify: (global image id, digest) pairs from every rank
     import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, [(g, f'digest-of-{g}') for g in mine])
+    merged = {g: d for p in parts for g, d in p}
+    q.put((rank, full, mine, t, merged, torch.get_num_threads()))
     dist.destroy_process_group()
 
 
@@ -57,8 +61,8 @@ def _run_world(world, n_gallery, n_images):
     return results
 
 
-@pytest.mark.parametrize('world,n_gallery,n_images', [(2, 11, 16), (2, 4, 3), (3, 10, 64)])
-def test_sharded_gallery_and_image_partition(world, n_gallery, n_images):
+@pytest.mark.parametrize('world,n_gallery,n_images', [(2, 11, 16), (2, 4, 3), (3, 10, 64), (8, 3207, 64)])     # the last: BASELINE configs[4]'s
+def test_sharded_gallery_and_image_partition(world, n_gallery, n_images):                                       # 8 ranks x 8 images, an uneven gallery (3200 + 7)
     try:
         results = _run_world(world, n_gallery, n_images)
     except Exception:            # a rendezvous port can be taken between _free_port() and bind: one retry
@@ -66,9 +70,10 @@ def test_sharded_gallery_and_image_partition(world, n_gallery, n_images):
     gal = torch.rand(n_gallery, 3, 8, 8, generator=torch.Generator().manual_seed(7))
     want = _fake_embed(gal)
     seen = []
-    for rank, full, mine, t in results:
+    for rank, full, mine, t, merged, _ in results:
         assert torch.equal(full, want), f'rank {rank}: gathered gallery differs from the single-rank gallery'
         assert t == float(world)
+        assert merged == {g: f'digest-of-{g}' for g in range(n_images)}      # every rank holds every image's digest after the gather
         seen += mine
     assert sorted(seen) == list(range(n_images))        # every image on exactly one rank
 
@@ -84,3 +89,10 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     assert cdist.shard_range(64, 3, 8) == (24, 32)       # BASELINE config 5: 8 images per GPU
     assert cdist.all_gather_rows(torch.ones(3, 2), 3, 0, 1).shape == (3, 2)
+
+
+def test_host_thread_share():
+    """bench.py caps every rank's host threads at cores // world (eight ranks on one node each synthesise and stage 403 MB of images
+    per step: uncapped they would run 8 x cores OpenMP threads)."""
+    import bench
+    assert bench.host_threads_for(1, 64) == 64 and bench.host_threads_for(8, 64) == 8 and bench.host_threads_for(8, 4) == 1

@@ -111,3 +111,35 @@ def test_planogram_evaluator_end_to_end(cuda):
     assert float(ev.evaluate(shelf, planogram)) == 1.0            # missing detection recovered by re-classification
     blank = shelf.clone(); blank[:, int(boxes[5, 1]):int(boxes[5, 3]), int(boxes[5, 0]):int(boxes[5, 2])] = 0.5
     assert abs(float(ev.evaluate(blank, planogram)) - 7 / 8) < 1e-6    # product really absent -> non-compliant slot
+
+
+def test_evaluate_batch_equals_per_image(cuda):
+    """The batched drop-in evaluation (PlanogramEvaluator.evaluate_batch, what `cvpce eval-planograms` runs over windows of 8
+    images) hands the comparator exactly what the reference-shaped per-image `evaluate` does (production.py:123-129): same
+    boxes, same labels, same verdicts -- images of one size share a detector / embedder / matcher pass, other sizes do not."""
+    from cvpce_amd import production, synthetic
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=40).to(cuda)
+    enc = synthetic.synthetic_macvgg(seed=1).to(cuda)
+    gal = synthetic.gallery_images(24, seed=17)
+    clf = production.Classifier(enc, synthetic.TensorGallery(gal, [f'sku{i % 6}' for i in range(24)]), device=cuda, emb_device=cuda,
+                                batch_size=8)
+    pg = production.ProposalGenerator(det, device=cuda, confidence_threshold=0.5)
+    ev = production.PlanogramEvaluator(pg, clf, production.PlanogramComparator())
+    imgs = [synthetic.shelf_image(60, 512, 640), synthetic.shelf_image(61, 512, 640), synthetic.shelf_image(62, 448, 512),
+            synthetic.shelf_image(63, 512, 640)]
+    single = []
+    for im in imgs:
+        boxes, crops = pg.generate_proposals_and_images(im)
+        single.append((boxes.cpu(), [a[0] for a in clf.classify(crops)]))
+    batch = ev.detect_and_classify_batch(imgs)
+    assert sum(len(b) for b, _ in single) > 20
+    for (b1, l1), (b2, l2) in zip(single, batch):
+        assert torch.equal(b1, b2) and l1 == l2
+    # planograms: each image's own detections, a third of them dropped and a few labels changed -> partial compliance
+    planos = []
+    for k, (b, l) in enumerate(single):
+        keep = [i for i in range(len(b)) if i % 3 != k % 3]
+        planos.append({'boxes': b[keep] * 0.5, 'labels': [('other' if i % 7 == 0 else l[i]) for i in keep]})
+    want = [float(ev.evaluate(im, p)) for im, p in zip(imgs, planos)]
+    got = [float(v) for v in ev.evaluate_batch(imgs, planos)]
+    assert got == want and any(0.0 < v < 1.0 for v in want), (got, want)

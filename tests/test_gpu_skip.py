@@ -120,8 +120,13 @@ def test_worklists_match_python_model(cuda):
             if skip:
                 ny = min(ty_n, -(-_extent(ey0, osh, og, h) // th))
                 nx = min(tx_n, -(-_extent(ex0, osh, og, w) // tw))
-            hi = (_extent(ey0, ish, ig, ih) << 16) | _extent(ex0, ish, ig, iw)
-            want += [(hi << 32) | (c << 16) | (ty << 8) | tx for ty in range(ny) for tx in range(nx)]
+            ext = (_extent(ey0, ish, ig, ih) << 12) | _extent(ex0, ish, ig, iw)
+            for ty in range(ny):
+                rows = 16                                        # conv-output rows of the tile that are not constant, rounded up to 4
+                if skip:
+                    act = min(th, _extent(ey0, osh, og, h) - ty * th)
+                    rows = min(16, (-(-act * 16 // th) + 3) // 4 * 4)
+                want += [(((rows << 24) | ext) << 32) | (c << 16) | (ty << 8) | tx for tx in range(nx)]
         assert counts[li] == len(want), (li, counts[li], len(want))
         assert lists[li, :len(want)].tolist() == want, li
     # the growth bookkeeping is an upper bound of the true extent of every tensor of the pass (a pixel beyond it is constant)

@@ -8,7 +8,7 @@ tag, prof, pmc = sys.argv[1], sys.argv[2], sys.argv[3]          # e.g. r01g prof
 def prof_name(k):    # rocprof kernel name -> the name ops.ConvProfile / bench.py use
     for p, n in (('void conv3x3_halo2_kernel', 'conv3x3_halo2_kernel'), ('void conv3x3_halo3_kernel', 'conv3x3_halo3_kernel'),
                  ('vgg_stem2_kernel', 'vgg_stem2_kernel')):
-        if k.startswith(p):
+        if k.startswith(p) or k.startswith('void ' + p):
             return n
     return None
 
@@ -50,6 +50,11 @@ with open(f'{root}/profiles/{tag}_pmc_hbm_traffic.md', 'w') as fo:
     fo.write('\n`hbm_traffic.json` holds the same figures keyed by the names bench.py uses for its conv profile\n'
              '(template instantiations that differ only in the fused pooling are merged, launch-weighted).\n')
 js = {pn: {'launches': n, 'read_bytes_per_launch': fb / n, 'write_bytes_per_launch': wb / n} for pn, (n, fb, wb) in byname.items()}
+# stamped with the library the counters were collected on (the .so that travelled to the GPU box = the one in the tree now, as long as
+# nothing was rebuilt in between): bench.py reports `roofline.traffic` only when the library it loads is this one
+import hashlib
+js['_library_sha256'] = hashlib.sha256(open(f'{root}/cvpce_amd/libcvpce_hip.so', 'rb').read()).hexdigest()
+js['_collected_as'] = tag
 json.dump(js, open(f'{root}/profiles/hbm_traffic.json', 'w'), indent=1)
 res = collections.defaultdict(dict)
 for kind in ('sq', 'tcc'):
