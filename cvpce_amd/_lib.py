@@ -50,7 +50,7 @@ SIGNATURES = {
                                   POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_pack_embed_input': (c_int, [_fp, _vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_crop_extents': (c_int, [_fp, _ip, c_int, c_int, c_int, c_int, _ip, _vp]),
-    'cvpce_embed_worklists': (c_int, [_ip, c_int, c_int, _vp, c_int, _vp, c_longlong, _ip, _vp]),
+    'cvpce_embed_worklists': (c_int, [_ip, c_int, c_int, ctypes.c_uint, _vp, c_int, _vp, c_longlong, _ip, _vp]),
     'cvpce_vgg_stem_fused_list': (c_int, [_vp, c_int, _vp, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp, _ip, _vp]),
     'cvpce_conv3x3_halo_list': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 9 + [_vp, _ip, _vp]),
     'cvpce_detect_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
@@ -88,7 +88,7 @@ def check(rc, what):
 
 class SkipLayer(ctypes.Structure):
     """`cvpce_skip_layer` of include/cvpce_amd.h."""
-    _fields_ = [(k, c_int) for k in ('H', 'W', 'tile_h', 'tile_w', 'out_shift', 'out_grow', 'in_H', 'in_W', 'in_shift', 'in_grow', 'skip')]
+    _fields_ = [(k, c_int) for k in ('H', 'W', 'tile_h', 'tile_w', 'out_ops', 'in_H', 'in_W', 'in_ops', 'skip')]
 
 
 def float3(vals):

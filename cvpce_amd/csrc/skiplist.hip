@@ -8,9 +8,10 @@
 //   * a tile all of whose OUTPUT pixels lie in the constant region of its crop is not computed and not stored,
 //   * a kernel that reads an input pixel in the constant region of its crop reads the constant crop's pixel instead
 //     (conv3x3_halo2.hip / conv3x3_halo3.hip: the image index of the patch DMA's per-lane offset).
-// Constant region of a tensor at stride 2^sh of the crop: rows >= e_y or columns >= e_x with e = min(size, ceil(e0 / 2^sh) + g),
-// e0 = the crop's content extent (cvpce_crop_extents), g = the growth the host accumulates (+1 per 3x3 conv, halved upwards
-// by a pool: an upper bound of the true extent, the same formula on the producer's and the consumer's side of a tensor).
+// Constant region of a tensor of the pass: rows >= e_y or columns >= e_x, where e is the crop's content extent e0
+// (cvpce_crop_extents) taken through the ops between the crop and that tensor -- a 3x3 conv grows it by 1, a 2x2 pool halves it
+// upwards -- and clamped to the tensor's size.  The op chain of the whole pass is one bit string (cvpce_embed_worklists `pool_mask`);
+// a tensor is named by how many ops precede it, so its producer and its consumers compute the same, exact, extent.
 //
 // This kernel turns the extents into one compacted, crop-major tile list per layer (device-resident counts: no host sync):
 //   entry = ((rows << 24 | ey_in << 12 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
@@ -24,26 +25,28 @@
 struct WorklistArgs {
     const int* ext0;                 // [n - 1][2] content rows / columns at the crop resolution S; image n - 1 is the constant crop
     int n, S, nl;
+    unsigned pool_mask;              // bit i: op i of the pass is a 2x2 pool (else a 3x3 conv)
     cvpce_skip_layer L[SKL_MAX_LAYERS];
     unsigned long long* lists;       // [nl][stride]
     long long stride;
-    int* counts;                     // [nl]
+    int* counts;                     // [2 * nl]: tiles listed per layer, then sixteenths of a tile's MFMA work actually performed per layer
 };
 
-__device__ __forceinline__ int skl_extent(int e0, int S, int sh, int g, int size) {
+__device__ __forceinline__ int skl_extent(int e0, int S, unsigned pool_mask, int nops, int size) {
     if (e0 >= S) return size;
-    const int e = ((e0 + (1 << sh) - 1) >> sh) + g;
+    int e = e0;
+    for (int i = 0; i < nops; ++i) e = ((pool_mask >> i) & 1u) ? (e + 1) >> 1 : e + 1;
     return e < size ? e : size;
 }
 
 __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
     __shared__ int s_cnt[1024];
-    __shared__ int s_base;
+    __shared__ int s_base, s_units;
     const cvpce_skip_layer L = a.L[blockIdx.x];
     const int tid = threadIdx.x;
     const int tiles_y = (L.H + L.tile_h - 1) / L.tile_h, tiles_x = (L.W + L.tile_w - 1) / L.tile_w;
     unsigned long long* list = a.lists + (long long)blockIdx.x * a.stride;
-    if (tid == 0) s_base = 0;
+    if (tid == 0) s_base = s_units = 0;
     __syncthreads();
     for (int n0 = 0; n0 < a.n; n0 += 1024) {
         const int n = n0 + tid;
@@ -53,14 +56,14 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
             const int ey0 = is_const ? a.S : a.ext0[2 * n], ex0 = is_const ? a.S : a.ext0[2 * n + 1];
             ny = tiles_y; nx = tiles_x;
             if (L.skip) {
-                const int eoy = skl_extent(ey0, a.S, L.out_shift, L.out_grow, L.H), eox = skl_extent(ex0, a.S, L.out_shift, L.out_grow, L.W);
+                const int eoy = skl_extent(ey0, a.S, a.pool_mask, L.out_ops, L.H), eox = skl_extent(ex0, a.S, a.pool_mask, L.out_ops, L.W);
                 eoy_ = eoy;
                 const int cy = (eoy + L.tile_h - 1) / L.tile_h, cx = (eox + L.tile_w - 1) / L.tile_w;   // tile row ty is computed iff ty * tile_h < eoy
                 ny = cy < tiles_y ? cy : tiles_y;
                 nx = cx < tiles_x ? cx : tiles_x;
             }
-            eiy = skl_extent(ey0, a.S, L.in_shift, L.in_grow, L.in_H);
-            eix = skl_extent(ex0, a.S, L.in_shift, L.in_grow, L.in_W);
+            eiy = skl_extent(ey0, a.S, a.pool_mask, L.in_ops, L.in_H);
+            eix = skl_extent(ex0, a.S, a.pool_mask, L.in_ops, L.in_W);
         }
         // exclusive scan of the per-crop tile counts (Hillis-Steele over the 1024 slots)
         const int cnt = ny * nx;
@@ -79,11 +82,12 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
         // entries of this thread's crop; blockIdx.y splits the crops among workgroups (every workgroup runs the same scan)
         if (n < a.n && (n % (int)gridDim.y) == (int)blockIdx.y) {
             const unsigned ext = ((unsigned)eiy << 12) | (unsigned)eix;
+            int units = 0;
             for (int j = 0; j < cnt; ++j) {
                 const int ty = j / nx, tx = j - ty * nx;
                 // active conv-output rows of this tile, in sixteenths of the tile height, rounded up to a multiple of 4
                 int rows = 16;
-                if (L.skip) {
+                if (L.skip >= 2) {
                     const int left = eoy_ - ty * L.tile_h;
                     const int act = left < L.tile_h ? left : L.tile_h;
                     rows = ((act * 16 + L.tile_h - 1) / L.tile_h + 3) & ~3;
@@ -91,29 +95,33 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
                 }
                 list[base + j] = ((unsigned long long)(((unsigned)rows << 24) | ext) << 32) |
                                  (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
+                units += rows < 16 ? rows + 1 : 16;          // a tile cut at `rows` streams patch rows 0 .. rows + 1: (rows + 1) / 16 of its MFMAs
             }
+            atomicAdd(&s_units, units);
         }
         __syncthreads();
     }
     if (tid == 0 && blockIdx.y == 0) a.counts[blockIdx.x] = s_base;
+    if (tid == 0) atomicAdd(&a.counts[a.nl + blockIdx.x], s_units);       // (summed over the workgroups that split the crops; zeroed by the host wrapper)
 }
 
-extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, const cvpce_skip_layer* layers, int n_layers,
+extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsigned pool_mask, const cvpce_skip_layer* layers, int n_layers,
                                      unsigned long long* lists, long long list_stride, int* counts, void* stream) {
     if (n_layers <= 0) return CVPCE_OK;
     if (!ext0 && n_images > 1) return CVPCE_ERR_ARG;
     if (!layers || !lists || !counts || n_layers > SKL_MAX_LAYERS || n_images <= 0 || n_images > 65535 || S <= 0 || S > 32767) return CVPCE_ERR_ARG;
     WorklistArgs a;
-    a.ext0 = ext0; a.n = n_images; a.S = S; a.nl = n_layers; a.lists = lists; a.stride = list_stride; a.counts = counts;
+    a.ext0 = ext0; a.n = n_images; a.S = S; a.nl = n_layers; a.pool_mask = pool_mask; a.lists = lists; a.stride = list_stride; a.counts = counts;
     for (int i = 0; i < n_layers; ++i) {
         const cvpce_skip_layer& l = layers[i];
         if (l.H <= 0 || l.W <= 0 || l.tile_h <= 0 || l.tile_w <= 0 || l.in_H <= 0 || l.in_W <= 0 || l.in_H > 4095 || l.in_W > 4095) return CVPCE_ERR_ARG;
-        if (l.in_shift < 0 || l.out_shift < 0 || l.in_shift > 15 || l.out_shift > 15 || l.in_grow < 0 || l.out_grow < 0) return CVPCE_ERR_ARG;
+        if (l.in_ops < 0 || l.out_ops < l.in_ops || l.out_ops > 32) return CVPCE_ERR_ARG;
         const long long ty = (l.H + l.tile_h - 1) / l.tile_h, tx = (l.W + l.tile_w - 1) / l.tile_w;
         if (ty > 255 || tx > 255 || ty * tx * n_images > list_stride) return CVPCE_ERR_ARG;
         a.L[i] = l;
     }
     const int split = n_images >= 64 ? 8 : 1;
+    if (hipMemsetAsync(counts + n_layers, 0, sizeof(int) * n_layers, (hipStream_t)stream) != hipSuccess) return CVPCE_ERR_LAUNCH;
     hipLaunchKernelGGL(embed_worklists_kernel, dim3(n_layers, split), dim3(1024), 0, (hipStream_t)stream, a);
     return cvpce_check_launch();
 }

@@ -37,6 +37,11 @@ FUSED_EMBED_BATCH = min(FUSED_EMBED_BATCH, FUSED_EMBED_MAX)        # (an over-la
 # with 0.5, so the part of the 256 x 256 embedder input below / right of the box content is the same constant in every crop; conv
 # tiles whose receptive field lies inside it are not computed (bit-identical results: tests/test_gpu_skip.py).  A/B switch.
 SKIP_PADDING = _os.environ.get('CVPCE_SKIP_PADDING', '1') != '0'
+# Cutting the LISTED tiles at their last non-constant row as well (the halo kernels stop streaming patch rows there) is built and
+# bit-exact (tests/test_gpu_skip.py runs both settings) but OFF: same-box A/B 31.16 vs 31.10 ms per 1 600 bench-shaped crops.  A cut tile
+# issues a third of the MFMAs per step against the same weight stream, and its steps become too short to hide the weight loads'
+# latency (conv4_2: 5.01 -> 4.77 ms at a third fewer MFMAs) -- profiles/r04_rejected_experiments.md.
+SKIP_ROWS = _os.environ.get('CVPCE_SKIP_ROWS', '0') != '0'
 
 
 def _passes(n, step, longest):
@@ -111,17 +116,19 @@ class MACVGGEngine:
 
     # ---- constant-padding tile skipping --------------------------------------------------------------------------------------
     def skip_plan(self, size):
-        """The work-list schedule for size x size inputs: [(kind, PackedConv | None, pool, mac)] with one `ops.skip_layer` each, or
-        None when this engine's plan is not stem + 3x3 halo convolutions with the MAC descriptors fused (then nothing is skipped).
-        Extent bookkeeping (include/cvpce_amd.h `cvpce_skip_layer`): a tensor at stride 2^sh of the crop is constant beyond
-        ceil(ext / 2^sh) + g; a 3x3 conv adds 1 to g, a 2x2 pool halves g upwards and adds 1 to sh."""
-        if size in self._skip_plans:
-            return self._skip_plans[size]
-        steps, layers = None, []
+        """The work-list schedule for size x size inputs: (steps [(kind, PackedConv | None, pool, mac, store)], one `ops.skip_layer`
+        per step, pool_mask), or None when this engine's plan is not stem + 3x3 halo convolutions with the MAC descriptors fused
+        (then nothing is skipped).  Extent bookkeeping (include/cvpce_amd.h `cvpce_skip_layer`): the pass is a chain of ops on
+        the crop -- conv (+1) and pool (halve upwards) -- and every tensor is named by the number of ops before it."""
+        key = (size, SKIP_ROWS)
+        if key in self._skip_plans:
+            return self._skip_plans[key]
+        steps, layers, chain = None, [], []
         if self.stem is not None and size % 16 == 0 and size <= 1024:
             steps = [('stem', None, True, False)]
-            h, sh, g = size // 2, 1, 1                       # conv1_1 (+1), conv1_2 (+1), pool1: ceil(2 / 2) = 1
-            layers.append(ops.skip_layer(h, h, 8, 8, sh, g, size, size, 0, 0, 1))
+            chain += [0, 0, 1]                               # conv1_1, conv1_2, pool1
+            h = size // 2
+            layers.append(ops.skip_layer(h, h, 8, 8, len(chain), size, size, 0, 1))
             plan = self.plan + [('desc', None)]
             i = 0
             while steps is not None and i < len(plan):
@@ -135,22 +142,27 @@ class MACVGGEngine:
                 pool = kind == 'conv_pool' or (mac and after == 'pool' and h % 2 == 0)
                 store = not mac or after is not None
                 th, tw = (16, 32) if pc.cout <= 128 else (16, 16)
-                og, osh, oh = g + 1, sh, h
+                in_ops, oh = len(chain), h
+                chain.append(0)
                 if pool:
-                    th, tw, og, osh, oh = th // 2, tw // 2, (og + 1) // 2, sh + 1, h // 2
+                    chain.append(1)
+                    th, tw, oh = th // 2, tw // 2, h // 2
                 if not store:
                     oh, th, tw = h, 16, 16
-                layers.append(ops.skip_layer(oh, oh, th, tw, osh, og, h, h, sh, g, 0 if mac else 1))
+                layers.append(ops.skip_layer(oh, oh, th, tw, len(chain), h, h, in_ops, 0 if mac else (2 if SKIP_ROWS else 1)))
                 steps.append(('conv', pc, pool, mac, store))
                 i += (3 if pool else 2) if mac else 1
                 if not mac and i < len(plan) and plan[i][0] != 'conv' and plan[i][0] != 'conv_pool':
                     steps = None                              # a stand-alone pool / descriptor: not this schedule
                     break
-                h, sh, g = oh, osh, og
+                h = oh
                 if h % 16 != 0 and i < len(plan):
                     steps = None
-        self._skip_plans[size] = None if steps is None else (steps, layers)
-        return self._skip_plans[size]
+            if steps is not None and len(chain) > 32:
+                steps = None
+        pool_mask = sum(1 << i for i, p in enumerate(chain) if p)
+        self._skip_plans[key] = None if steps is None else (steps, layers, pool_mask)
+        return self._skip_plans[key]
 
     def const_crop(self, mean, std, channels, size):
         """The all-padding crop in the layout the crop kernel writes: made BY the crop kernel from a zero-area box, so its
@@ -164,14 +176,15 @@ class MACVGGEngine:
 
     def _embed_pass_skip(self, xb, ext, const_in, sched):
         """One pass of the schedule over work lists: xb (n,S,S,c) + the constant crop as image n -> MAC descriptor (n,1024)."""
-        steps, layers = sched
+        steps, layers, pool_mask = sched
         n = xb.shape[0]
-        lists, counts = ops.embed_worklists(ext, n + 1, xb.shape[1], layers, (xb.shape[1] // 16) ** 2)
+        lists, counts = ops.embed_worklists(ext, n + 1, xb.shape[1], pool_mask, layers, (xb.shape[1] // 16) ** 2)
         desc = torch.zeros((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
         off = 0
         t = ops.vgg_stem_list(xb, const_in, self.stem, lists[0], counts[0:1])
         for li, (kind, pc, pool, mac, store) in enumerate(steps[1:], start=1):
-            t = ops.conv2d_list(t, pc, lists[li], counts[li:li + 1], act=1, pool=pool, mac=desc if mac else None, mac_off=off, store=store)
+            t = ops.conv2d_list(t, pc, lists[li], counts[li:li + 1], act=1, pool=pool, mac=desc if mac else None, mac_off=off, store=store,
+                                units=counts[len(steps) + li:len(steps) + li + 1])
             if mac:
                 off += pc.cout
         return desc[:n]

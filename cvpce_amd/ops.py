@@ -388,23 +388,24 @@ def crop_extents(boxes, count, h0, w0, size=256, out=None):
     return out
 
 
-def skip_layer(h, w, tile_h, tile_w, out_shift, out_grow, in_h, in_w, in_shift, in_grow, skip):
+def skip_layer(h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip):
     """One `cvpce_skip_layer` as the flat int list `embed_worklists` takes."""
-    return [int(v) for v in (h, w, tile_h, tile_w, out_shift, out_grow, in_h, in_w, in_shift, in_grow, skip)]
+    return [int(v) for v in (h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip)]
 
 
-def embed_worklists(ext0, n_images, size, layers, max_tiles):
-    """ext0 (n_images - 1, 2) int32 (the last image is the implied constant crop); layers: list of `skip_layer` ->
-    (lists (L, n_images * max_tiles) int64, counts (L,) int32), all on the device, no synchronisation."""
+def embed_worklists(ext0, n_images, size, pool_mask, layers, max_tiles):
+    """ext0 (n_images - 1, 2) int32 (the last image is the implied constant crop); pool_mask: the pass's op chain (bit i: op i is
+    a 2x2 pool, else a 3x3 conv); layers: list of `skip_layer` -> (lists (L, n_images * max_tiles) int64, counts (2 L,) int32:
+    tiles per layer, then the layers' MFMA work in sixteenths of a tile), all on the device, no synchronisation."""
     _need_cuda(ext0)
     dev = ext0.device if ext0 is not None else torch.device('cuda', torch.cuda.current_device())
     lists = torch.empty((len(layers), n_images * max_tiles), dtype=torch.int64, device=dev)
-    counts = torch.empty((len(layers),), dtype=torch.int32, device=dev)
-    T.embed_worklists(ext0, int(n_images), int(size), [v for l in layers for v in l], lists, counts)
+    counts = torch.empty((2 * len(layers),), dtype=torch.int32, device=dev)
+    T.embed_worklists(ext0, int(n_images), int(size), int(pool_mask), [v for l in layers for v in l], lists, counts)
     return lists, counts
 
 
-def vgg_stem_list(x, const_in, ps, work, count):
+def vgg_stem_list(x, const_in, ps, work, count, units=None):
     """`vgg_stem` over a work list: x (N-1,H,W,4|8) + the constant crop const_in (H,W,c) -> (N,H/2,W/2,64)."""
     _need_cuda(x, const_in, work, count)
     assert x.dtype == BF16 and x.is_contiguous() and x.shape[3] in (4, 8) and const_in.is_contiguous()
@@ -417,11 +418,11 @@ def vgg_stem_list(x, const_in, ps, work, count):
     T.vgg_stem_fused_list(x, const_in, ps.w1, ps.b1, ps.w2, ps.b2, out, work, count)
     if prof is not None:
         e1.record()
-        prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n1 * h * w, e0, e1, count, ps.flops_per_pixel * 256))
+        prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n1 * h * w, e0, e1, count, ps.flops_per_pixel * 256))   # (the stem computes whole tiles)
     return out
 
 
-def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True):
+def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True, units=None):
     """3x3 / s1 / p1 conv (+ReLU, + fused MaxPool2d(2,2), + fused MAC descriptor) over a work list; x (N,H,W,Cin) with the
     constant crop as image N - 1.  Returns the output tensor (None with store=False)."""
     _need_cuda(x, work, count, mac)
@@ -439,8 +440,9 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
     if prof is not None:
         e1.record()
         wide = pc.cout <= 128
-        prof.records.append(('conv3x3_halo3_kernel' if wide else 'conv3x3_halo2_kernel', 2.0 * (n - 1) * h * w * pc.cout * 9 * pc.cin, e0, e1,
-                             count, 2.0 * 16 * (32 if wide else 16) * pc.cout * 9 * pc.cin))
+        tile_flops = 2.0 * 16 * (32 if wide else 16) * pc.cout * 9 * pc.cin
+        prof.records.append(('conv3x3_halo3_kernel' if wide else 'conv3x3_halo2_kernel', 2.0 * (n - 1) * h * w * pc.cout * 9 * pc.cin, e0, e1)
+                            + ((units, tile_flops / 16) if units is not None else (count, tile_flops)))
     return out
 
 

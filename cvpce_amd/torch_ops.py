@@ -180,16 +180,16 @@ def _crop_extents(boxes, count, h0, w0, size, ext):
     check(lib.cvpce_crop_extents(_p(boxes), _p(count), boxes.shape[0], h0, w0, size, _p(ext), _stream()), 'cvpce_crop_extents')
 
 
-@_op('embed_worklists(Tensor? ext0, int n_images, int size, int[] layers, Tensor(a!) lists, Tensor(b!) counts) -> ()')
-def _embed_worklists(ext0, n_images, size, layers, lists, counts):
-    """layers: 11 ints per layer in the field order of `cvpce_skip_layer`; lists (n_layers, stride) int64; counts (n_layers,) int32."""
+@_op('embed_worklists(Tensor? ext0, int n_images, int size, int pool_mask, int[] layers, Tensor(a!) lists, Tensor(b!) counts) -> ()')
+def _embed_worklists(ext0, n_images, size, pool_mask, layers, lists, counts):
+    """layers: 9 ints per layer in the field order of `cvpce_skip_layer`; lists (n_layers, stride) int64; counts (2 * n_layers,) int32 (tiles, then row units)."""
     nf = len(_lib.SkipLayer._fields_)
     nl = len(layers) // nf
     if len(layers) != nl * nf or lists.dtype != torch.int64 or not lists.is_contiguous() or lists.shape[0] != nl or counts.dtype != torch.int32 \
-            or counts.numel() != nl or (ext0 is not None and (ext0.dtype != torch.int32 or not ext0.is_contiguous() or ext0.numel() < 2 * (n_images - 1))):
+            or counts.numel() != 2 * nl or (ext0 is not None and (ext0.dtype != torch.int32 or not ext0.is_contiguous() or ext0.numel() < 2 * (n_images - 1))):
         raise RuntimeError('embed_worklists: bad argument shapes / types')
     arr = (_lib.SkipLayer * nl)(*[_lib.SkipLayer(*[int(v) for v in layers[i * nf:(i + 1) * nf]]) for i in range(nl)])
-    check(lib.cvpce_embed_worklists(_p(ext0), n_images, size, ctypes.cast(arr, ctypes.c_void_p), nl, _p(lists), lists.shape[1], _p(counts), _stream()),
+    check(lib.cvpce_embed_worklists(_p(ext0), n_images, size, pool_mask, ctypes.cast(arr, ctypes.c_void_p), nl, _p(lists), lists.shape[1], _p(counts), _stream()),
           'cvpce_embed_worklists')
 
 

@@ -171,24 +171,27 @@ int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int t
  * cvpce_crop_resize writes EXACTLY the pad constant to every pixel with oy >= rows or ox >= cols.  p >= *count_dev: (S, S). */
 int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int H0, int W0, int S, int* ext_out,
                        void* stream);
-/* One layer of the pass for cvpce_embed_worklists.  A tensor at stride 2^shift of the crop is constant on rows >= e_y /
- * columns >= e_x with e = min(size, ceil(ext / 2^shift) + grow); `grow` is accumulated by the host (+1 per 3x3 conv; a 2x2
- * pool halves it upwards and adds 1 to shift) and must be the same number wherever the same tensor is produced and consumed. */
+/* One layer of the pass for cvpce_embed_worklists.  The pass is a chain of ops on the crop -- 3x3 convs (a crop's content extent
+ * grows by 1) and 2x2 pools (it halves, upwards) -- given as `pool_mask` (bit i set: op i is a pool); a tensor is named by the
+ * number of ops before it, and is constant on rows >= e_y / columns >= e_x, e = min(size, the crop's extent through those ops). */
 typedef struct {
     int H, W;                  /* the layer's OUTPUT tensor (after a fused pool) */
     int tile_h, tile_w;        /* the kernel's tile in output-tensor pixels (halo2 16x16, pooled 8x8; halo3 16x32, pooled 8x16; stem 8x8) */
-    int out_shift, out_grow;   /* extent formula of the output tensor */
+    int out_ops;               /* ops of the pass up to and including this layer (= the name of its output tensor) */
     int in_H, in_W;            /* the layer's INPUT tensor */
-    int in_shift, in_grow;     /* ... and its extent formula */
-    int skip;                  /* 0: list every tile (layers whose epilogue needs every tile: the fused MAC maximum) */
+    int in_ops;                /* ... and its name */
+    int skip;                  /* 0: list every tile (layers whose epilogue needs every tile: the fused MAC maximum); 1: leave out the tiles
+                                  that are wholly constant; 2: ... and cut the listed tiles at their last non-constant row (`rows`) */
 } cvpce_skip_layer;
 /* ext0 [n_images - 1][2] (cvpce_crop_extents; the constant crop, image n_images - 1, is implied), layers [host] ->
  * lists[l * list_stride + i] for i < counts[l] (device): the tiles layer l computes, crop-major,
  *   entry = ((rows << 24 | ey_in << 12 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
  * (ey_in / ex_in < 4096: the INPUT tensor's extents of crop n; rows in {4, 8, 12, 16}: the tile's conv-output rows that are not
  * wholly constant, rounded up to 4 -- the halo kernels compute only those, the rest of the tile is neither computed nor stored)
- * list_stride >= n_images * tiles of the largest layer.  No host synchronisation: the kernels read counts[l] themselves. */
-int cvpce_embed_worklists(const int* ext0, int n_images, int S, const cvpce_skip_layer* layers, int n_layers,
+ * list_stride >= n_images * tiles of the largest layer.  No host synchronisation: the kernels read counts[l] themselves.
+ * counts has 2 * n_layers entries: counts[n_layers + l] = the MFMA work layer l performs, in sixteenths of a full tile (a tile cut
+ * at `rows` < 16 streams rows + 1 of its 16 row groups) -- what `roofline` counts as executed FLOPs. */
+int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsigned pool_mask, const cvpce_skip_layer* layers, int n_layers,
                           unsigned long long* lists, long long list_stride, int* counts, void* stream);
 /* cvpce_vgg_stem_fused over a work list (tile = 8x8 output pixels).  `in` holds images 0 .. N-2, `const_in` (one image in the
  * same layout) is read as image N - 1. */

@@ -92,60 +92,66 @@ def test_crop_extents_and_exact_padding(cuda):
     assert torch.equal(e2[:5], ext[:5]) and (e2[5:] == S).all()
 
 
-def _extent(e0, sh, g, size):
+def _extent(e0, pool_mask, nops, size):
+    """include/cvpce_amd.h: the crop's content extent through the first `nops` ops of the pass (conv: +1, pool: halve upwards)."""
     if e0 >= S:
         return size
-    return min(size, -(-e0 // (1 << sh)) + g)
+    e = e0
+    for i in range(nops):
+        e = (e + 1) // 2 if (pool_mask >> i) & 1 else e + 1
+    return min(size, e)
 
 
-def test_worklists_match_python_model(cuda):
+@pytest.fixture(params=[False, True], ids=['tiles', 'tiles+rows'])
+def skip_rows(request):
+    """Both settings of the row-level cut (classification.SKIP_ROWS; off by default: measured no faster)."""
+    from cvpce_amd.models import classification as C
+    old, C.SKIP_ROWS = C.SKIP_ROWS, request.param
+    yield request.param
+    C.SKIP_ROWS = old
+
+
+def test_worklists_match_python_model(cuda, skip_rows):
     from cvpce_amd import ops, synthetic
     enc = synthetic.synthetic_macvgg(seed=1).cuda()
-    steps, layers = enc.engine().skip_plan(S)
-    assert len(layers) == 12 and [l[-1] for l in layers] == [1] * 8 + [0] + [1, 1] + [0]      # conv4_3 / conv5_3 carry the MAC maximum: never skipped
+    steps, layers, pool_mask = enc.engine().skip_plan(S)
+    m = 2 if skip_rows else 1
+    assert len(layers) == 12 and [l[-1] for l in layers] == [1] + [m] * 7 + [0] + [m, m] + [0]      # conv4_3 / conv5_3 carry the MAC maximum: never skipped
+    # the op chain of VGG16 cfg 'D' up to relu5_3: 2 convs, pool, 2 convs, pool, 3 convs, pool, 3 convs, pool, 3 convs
+    assert [(pool_mask >> i) & 1 for i in range(17)] == [0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]
+    assert [l[4] for l in layers] == [3, 4, 6, 7, 8, 10, 11, 12, 14, 15, 16, 17] and [l[7] for l in layers] == [0, 3, 4, 6, 7, 8, 10, 11, 12, 14, 15, 16]
     g = torch.Generator().manual_seed(3)
     n = 131
     ext = torch.stack((torch.randint(1, S + 1, (n,), generator=g), torch.full((n,), S)), dim=1).to(torch.int32)
     ext[::3] = ext[::3].flip(1)                                  # tall boxes: columns
     ext[5] = torch.tensor([S, S]); ext[6] = torch.tensor([0, 0]); ext[7] = torch.tensor([1, S]); ext[8] = torch.tensor([S, 255])
-    lists, counts = ops.embed_worklists(ext.cuda(), n + 1, S, layers, 256)
+    lists, counts = ops.embed_worklists(ext.cuda(), n + 1, S, pool_mask, layers, 256)
     lists, counts = lists.cpu(), counts.cpu().tolist()
     allext = ext.tolist() + [[S, S]]
     for li, L in enumerate(layers):
-        h, w, th, tw, osh, og, ih, iw, ish, ig, skip = L
+        h, w, th, tw, out_ops, ih, iw, in_ops, skip = L
         ty_n, tx_n = -(-h // th), -(-w // tw)
         want = []
         for c, (ey0, ex0) in enumerate(allext):
             ny, nx = ty_n, tx_n
             if skip:
-                ny = min(ty_n, -(-_extent(ey0, osh, og, h) // th))
-                nx = min(tx_n, -(-_extent(ex0, osh, og, w) // tw))
-            ext = (_extent(ey0, ish, ig, ih) << 12) | _extent(ex0, ish, ig, iw)
+                ny = min(ty_n, -(-_extent(ey0, pool_mask, out_ops, h) // th))
+                nx = min(tx_n, -(-_extent(ex0, pool_mask, out_ops, w) // tw))
+            ext_in = (_extent(ey0, pool_mask, in_ops, ih) << 12) | _extent(ex0, pool_mask, in_ops, iw)
             for ty in range(ny):
                 rows = 16                                        # conv-output rows of the tile that are not constant, rounded up to 4
-                if skip:
-                    act = min(th, _extent(ey0, osh, og, h) - ty * th)
+                if skip >= 2:
+                    act = min(th, _extent(ey0, pool_mask, out_ops, h) - ty * th)
                     rows = min(16, (-(-act * 16 // th) + 3) // 4 * 4)
-                want += [(((rows << 24) | ext) << 32) | (c << 16) | (ty << 8) | tx for tx in range(nx)]
+                want += [(((rows << 24) | ext_in) << 32) | (c << 16) | (ty << 8) | tx for tx in range(nx)]
         assert counts[li] == len(want), (li, counts[li], len(want))
+        rows_of = [(e >> 56) & 0xFF for e in want]
+        assert counts[len(layers) + li] == sum(r + 1 if r < 16 else 16 for r in rows_of), li       # MFMA work in sixteenths of a tile
         assert lists[li, :len(want)].tolist() == want, li
-    # the growth bookkeeping is an upper bound of the true extent of every tensor of the pass (a pixel beyond it is constant)
-    for e0 in range(1, S + 1):
-        true = e0
-        for li, L in enumerate(layers):
-            h, w, th, tw, osh, og, ih, iw, ish, ig, skip = L
-            assert _extent(e0, ish, ig, ih) >= min(ih, true), (li, e0)
-            if li == 0:
-                true = -(-(true + 2) // 2)                      # conv1_1, conv1_2, pool1
-            else:
-                pooled = h * 2 == ih
-                true = -(-(true + 1) // 2) if pooled else true + 1
-            true = min(true, h)
-            assert _extent(e0, osh, og, h) >= true, (li, e0)
 
 
 @pytest.mark.parametrize('batch_norm', [False, True])
-def test_embedding_is_bit_identical_with_skipping(cuda, batch_norm):
+def test_embedding_is_bit_identical_with_skipping(cuda, batch_norm, skip_rows):
     from cvpce_amd import ops, synthetic
     from cvpce_amd.models import classification as C
     enc = synthetic.synthetic_macvgg(seed=1, batch_norm=batch_norm).cuda()
@@ -181,7 +187,7 @@ def test_embedding_is_bit_identical_with_skipping(cuda, batch_norm):
     assert torch.equal(eng.embed_packed(crops, ext=loose, const_in=const), plain)
 
 
-def test_multi_pass_and_all_padding(cuda):
+def test_multi_pass_and_all_padding(cuda, skip_rows):
     """More crops than one pass of the schedule takes (the constant crop rides at the end of EVERY pass), all of one shape like
     the bench's workload, plus degenerate boxes (an all-padding crop: every tile is skipped)."""
     from cvpce_amd import ops, synthetic
