@@ -350,6 +350,36 @@ extern "C" int cvpce_crop_extents(const float* boxes, const int* count_dev, int 
     return cvpce_check_launch();
 }
 
+// Content extent of crops that are already materialised as (B,3,S,S) f32 tensors (the reference-shaped `Classifier.classify`
+// input, production.py:57-74): ext[b] = (rows, cols) such that every pixel with y >= rows or x >= cols equals `pad` in all three
+// channels -- found by looking at the data, so it holds for any tensor (crops made by cvpce_crop_resize carry exact 0.5 padding;
+// a tensor without constant borders simply gets (S, S)).  One workgroup per (row, crop); ext_out is zeroed by the entry point.
+__global__ void pad_extents_kernel(const float* __restrict__ in, int S, float pad, int* __restrict__ ext) {
+    const int y = blockIdx.x, b = blockIdx.y;
+    const float* p = in + (size_t)b * 3 * S * S + (size_t)y * S;
+    int mx = 0;
+    for (int x = threadIdx.x; x < S; x += blockDim.x)
+        if (p[x] != pad || p[(size_t)S * S + x] != pad || p[2 * (size_t)S * S + x] != pad) mx = x + 1;
+    __shared__ int smax;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    if (mx) atomicMax(&smax, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && smax) {
+        atomicMax(&ext[2 * b], y + 1);
+        atomicMax(&ext[2 * b + 1], smax);
+    }
+}
+
+extern "C" int cvpce_pad_extents(const float* in, int B, int S, float pad, int* ext_out, void* stream) {
+    if (!in || !ext_out || S <= 0) return CVPCE_ERR_ARG;
+    if (B <= 0) return CVPCE_OK;
+    if (B > 65535) return CVPCE_ERR_ARG;
+    if (hipMemsetAsync(ext_out, 0, sizeof(int) * 2 * (size_t)B, (hipStream_t)stream) != hipSuccess) return CVPCE_ERR_LAUNCH;
+    hipLaunchKernelGGL(pad_extents_kernel, dim3(S, B), dim3(S < 256 ? 64 : 256), 0, (hipStream_t)stream, in, S, pad, ext_out);
+    return cvpce_check_launch();
+}
+
 // (B,3,S,S) f32 NCHW -> NHWC8 bf16 with optional scale_to_tanh then (x - mean) / std.
 __global__ void pack_embed_input_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long npix, int SS,
                                         int to_tanh, float m0, float m1, float m2, float s0, float s1, float s2) {

@@ -388,6 +388,14 @@ def crop_extents(boxes, count, h0, w0, size=256, out=None):
     return out
 
 
+def pad_extents(images, pad=0.5):
+    """(B,3,S,S) f32 crops -> (B,2) int32: rows / columns beyond which every pixel equals `pad` in all channels (read off the data)."""
+    _need_cuda(images)
+    ext = torch.empty((images.shape[0], 2), dtype=torch.int32, device=images.device)
+    T.pad_extents(images, float(pad), ext)
+    return ext
+
+
 def skip_layer(h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip):
     """One `cvpce_skip_layer` as the flat int list `embed_worklists` takes."""
     return [int(v) for v in (h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip)]

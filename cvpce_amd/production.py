@@ -196,9 +196,15 @@ class Classifier:
         step = max(self.batch_size, ENGINE_BATCH)
         for i in range(0, len(images), step):
             batch = images[i:i + step].to(device=self.device)
-            packed = ops.pack_embed_input(batch, True, getattr(self.encoder, 'input_mean', TANH_MEAN),
-                                          getattr(self.encoder, 'input_std', TANH_STD))  # scale_to_tanh + the encoder's own normalisation, fused
-            emb = eng.embed_packed(packed)
+            mean, std = getattr(self.encoder, 'input_mean', TANH_MEAN), getattr(self.encoder, 'input_std', TANH_STD)
+            packed = ops.pack_embed_input(batch, True, mean, std)  # scale_to_tanh + the encoder's own normalisation, fused
+            if hasattr(eng, 'skip_plan') and batch.dim() == 4 and batch.shape[2] == batch.shape[3] and eng.skip_plan(batch.shape[2]) is not None:
+                # crops made by resize_for_classification carry a constant 0.5 border below / right of the box content
+                # (datautils.py:232-239): the embedder skips the tiles that lie in it -- the extents are read off the crops
+                b32 = batch.to(torch.float32).contiguous()
+                emb = eng.embed_packed(packed, ext=ops.pad_extents(b32, 0.5), const_in=eng.const_crop(mean, std, 8, batch.shape[2]))
+            else:
+                emb = eng.embed_packed(packed)
             if return_embedding:
                 embs.append(emb.to(device=self.emb_device))
             nearest = self.match(emb).tolist()

@@ -180,6 +180,14 @@ def _crop_extents(boxes, count, h0, w0, size, ext):
     check(lib.cvpce_crop_extents(_p(boxes), _p(count), boxes.shape[0], h0, w0, size, _p(ext), _stream()), 'cvpce_crop_extents')
 
 
+@_op('pad_extents(Tensor images, float pad, Tensor(a!) ext) -> ()')
+def _pad_extents(images, pad, ext):
+    if images.dtype != torch.float32 or not images.is_contiguous() or images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3] \
+            or ext.dtype != torch.int32 or not ext.is_contiguous() or ext.numel() < 2 * images.shape[0]:
+        raise RuntimeError('pad_extents: images (B,3,S,S) float32 contiguous, ext (B,2) int32')
+    check(lib.cvpce_pad_extents(_p(images), images.shape[0], images.shape[2], pad, _p(ext), _stream()), 'cvpce_pad_extents')
+
+
 @_op('embed_worklists(Tensor? ext0, int n_images, int size, int pool_mask, int[] layers, Tensor(a!) lists, Tensor(b!) counts) -> ()')
 def _embed_worklists(ext0, n_images, size, pool_mask, layers, lists, counts):
     """layers: 9 ints per layer in the field order of `cvpce_skip_layer`; lists (n_layers, stride) int64; counts (2 * n_layers,) int32 (tiles, then row units)."""

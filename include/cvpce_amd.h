@@ -171,6 +171,10 @@ int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int t
  * cvpce_crop_resize writes EXACTLY the pad constant to every pixel with oy >= rows or ox >= cols.  p >= *count_dev: (S, S). */
 int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int H0, int W0, int S, int* ext_out,
                        void* stream);
+/* The same extents read off crops that already exist as (B,3,S,S) f32 tensors (the input of Classifier.classify,
+ * production.py:57-74): every pixel with y >= rows or x >= cols equals `pad` (0.5) in all three channels.  Data-driven: a tensor
+ * without constant borders gets (S, S). */
+int cvpce_pad_extents(const float* in, int B, int S, float pad, int* ext_out, void* stream);
 /* One layer of the pass for cvpce_embed_worklists.  The pass is a chain of ops on the crop -- 3x3 convs (a crop's content extent
  * grows by 1) and 2x2 pools (it halves, upwards) -- given as `pool_mask` (bit i set: op i is a pool); a tensor is named by the
  * number of ops before it, and is constant on rows >= e_y / columns >= e_x, e = min(size, the crop's extent through those ops). */

@@ -40,6 +40,26 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 
+FITTED_HEAD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fitted_head.pt')
+
+
+def fitted_detector(detections_per_img, precision='bf16'):
+    """The detector whose RetinaNet head was FITTED on structured shelf scenes (tests/golden/fit_head.py -> fitted_head.pt: the
+    trained head tensors over the seeded base `synthetic_gln(seed=0, residual_gain=...)`): unlike the random-init detector it
+    finds the products, so AP / AR against the TRUE boxes is a non-vacuous figure and its score field is bimodal like a trained
+    detector's.  -> (model on the CPU, its reference-format state dict for the oracle, the fixture's recipe)."""
+    from cvpce_amd import synthetic
+    fx = torch.load(FITTED_HEAD, map_location='cpu')
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=detections_per_img, residual_gain=fx['recipe']['residual_gain'], calibrate=False,
+                                  precision=precision)
+    sd = det.state_dict()
+    for k, v in fx['tensors'].items():
+        assert k in sd and sd[k].shape == v.shape, k
+        sd[k] = v.to(torch.float32)
+    det.load_state_dict(sd)
+    return det, {k: v.clone() for k, v in det.state_dict().items()}, fx['recipe']
+
+
 def box_iou(a, b):
     area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
     area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
@@ -153,12 +173,18 @@ def _detection_report(hip, orc, shelves):
                       'ap50_area_hip': pa_h, 'ap50_area_oracle': pa_o, 'delta_area_pt': 100 * (pa_h - pa_o),
                       'note': 'the oracle scored against itself has recall exactly 1.0 and 11-point AP 1.0; any detector that misses one box '
                               'is capped at 10/11, so delta_pt is ~ -9 pt for every mode: delta_area_pt is the informative figure'},
-        'gt': {'ap50_hip': g_h[0.5]['ap'], 'ap50_oracle': g_o[0.5]['ap'], 'delta_pt': 100 * (g_h[0.5]['ap'] - g_o[0.5]['ap'])}}
+        'gt': {'ap50_hip': g_h[0.5]['ap'], 'ap50_oracle': g_o[0.5]['ap'], 'delta_pt': 100 * (g_h[0.5]['ap'] - g_o[0.5]['ap']),
+               'ap75_hip': g_h[0.75]['ap'], 'ap75_oracle': g_o[0.75]['ap'], 'delta75_pt': 100 * (g_h[0.75]['ap'] - g_o[0.75]['ap']),
+               'ar300_hip': g_h[0.5]['ar_300'], 'ar300_oracle': g_o[0.5]['ar_300'], 'delta_ar300_pt': 100 * (g_h[0.5]['ar_300'] - g_o[0.5]['ar_300']),
+               'ap50_area_hip': _ap_area(gt, hb, hs, 0.5)[0], 'ap50_area_oracle': _ap_area(gt, ob, os_, 0.5)[0],
+               'true_boxes': sum(len(g_) for g_ in gt),
+               'note': 'AP / AR300 of BOTH detectors against the pasted products\' TRUE boxes (cvpce/proposals_eval.py:19-48 with cvpce/metrics.py); '
+                       'ap50 = the reference\'s 11-point AP (steps of 1/11 = 9.09 pt), ap50_area = area under the same precision / recall curve'}}
 
 
 @torch.no_grad()
 def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
-        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None, precisions=('bf16',)):
+        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None, precisions=('bf16',), detector='random'):
     """precisions: detector storage modes to measure ('bf16' = the default schedule, 'fp16' = the accuracy mode); the oracle
     side is computed once.  The report's top-level `detection` / `matching` are those of precisions[0]; every mode's figures
     are under `by_precision`."""
@@ -167,9 +193,12 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
     log = log or (lambda *a: None)
     dev = torch.device('cuda:0')
     t_start = time.perf_counter()
-    det0 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain)
+    if detector == 'fitted':
+        det0, det_sd, recipe = fitted_detector(dpi)
+    else:
+        det0 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain)
+        det_sd = {k_: v.clone() for k_, v in det0.state_dict().items()}
     enc = synthetic.synthetic_macvgg(seed=1)
-    det_sd = {k_: v.clone() for k_, v in det0.state_dict().items()}
     enc_sd = {k_: v.clone() for k_, v in enc.state_dict().items()}
     enc = enc.to(dev)
     galleries = tuple(sorted(int(g) for g in galleries))
@@ -182,8 +211,11 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
     orc_gal = oracle_embed(gal_tanh, enc_sd, oracle_device)
     log(f'[accuracy] oracle gallery embedded on {oracle_device} ({time.perf_counter() - t:.1f} s)')
     report = {'n_images': n_images, 'image_size': image_size, 'detections_per_img': dpi, 'oracle_device_embedder': oracle_device,
-              'detector_residual_gain': residual_gain, 'detector_precisions': list(precisions),
-              'data': 'structured shelves (cvpce_amd.synthetic.structured_shelf), seeded random-init weights'}
+              'detector_residual_gain': residual_gain, 'detector_precisions': list(precisions), 'detector': detector,
+              'data': 'structured shelves (cvpce_amd.synthetic.structured_shelf), seeded random-init weights'
+                      + ('; detector head fitted on such scenes (tests/golden/fit_head.py)' if detector == 'fitted' else '')}
+    if detector == 'fitted':
+        report['fitted_head_recipe'] = recipe
     if oracle_device != 'cpu':                                           # the GPU run of the oracle code vs its CPU run
         chk = oracle_embed(gal_tanh[:8], enc_sd, 'cpu')
         report['oracle_cuda_vs_cpu_max_abs'] = float((chk - orc_gal[:8]).abs().max())
@@ -204,7 +236,8 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
     report['by_precision'] = {}
     emu = None
     for prec in precisions:
-        det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain, precision=prec).to(dev)
+        det = (fitted_detector(dpi, prec)[0] if detector == 'fitted'
+               else synthetic.synthetic_gln(seed=0, detections_per_img=dpi, residual_gain=residual_gain, precision=prec)).to(dev)
         pipe = production.BatchedPipeline(det, first, 0.5)
         hip = []
         for s in range(0, n_images, images_per_batch):
@@ -250,13 +283,27 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
             crops.append(ocrop.crop_boxes(shelves[n][0], oc[j:j + 1])[0])
         q_orc = oracle_embed(ocrop.scale_to_tanh(torch.stack(crops)), enc_sd, oracle_device) if crops else torch.empty(0, 1024)
         log(f'[accuracy] {prec}: oracle crop+embed of {len(sel)} paired detections ({time.perf_counter() - t:.1f} s)')
+        # the true product under each paired detection (the pasted box it overlaps at IoU > 0.5), if any: end-to-end top-1 accuracy
+        # of BOTH pipelines (own box -> own crop -> own embedding -> own nearest neighbour) against the pasted product's id
+        true_id = []
+        for n, i, j in sel:
+            oc = orc[n]['boxes'][orc[n]['scores'] > 0.5]
+            iou = box_iou(oc[j:j + 1], shelves[n][1])[0] if len(shelves[n][1]) else torch.zeros(0)
+            true_id.append(int(shelves[n][2][int(iou.argmax())]) if len(iou) and float(iou.max()) > 0.5 else -1)
+        true_id = torch.tensor(true_id, dtype=torch.int64)
+        on_product = true_id >= 0
         for g in galleries:
             o_idx = omatch.nearest_neighbors(orc_gal[:g], q_orc, min(k, g)) if len(q_orc) else torch.empty(0, k, dtype=torch.int64)
             for md in match_dtypes:
                 h_idx = torch.stack([hip[n]['idx'][(g, md)][i] for n, i, j in sel]) if sel else torch.empty(0, k, dtype=torch.int64)
                 top1 = (h_idx[:, 0] == o_idx[:, 0]).float().mean().item() if len(sel) else None
                 topk = (h_idx == o_idx[:, :1]).any(dim=1).float().mean().item() if len(sel) else None
-                rp['matching_pairs'][f'G{g}_{md}'] = {'n': len(sel), 'top1_agree': top1, f'top{k}_contains_oracle_top1': topk}
+                e = {'n': len(sel), 'top1_agree': top1, f'top{k}_contains_oracle_top1': topk}
+                if int(on_product.sum()):
+                    a_h = (h_idx[on_product, 0] == true_id[on_product]).float().mean().item()
+                    a_o = (o_idx[on_product, 0] == true_id[on_product]).float().mean().item()
+                    e['vs_true_product'] = {'n': int(on_product.sum()), 'top1_acc_hip': a_h, 'top1_acc_oracle': a_o, 'delta_pt': 100 * (a_h - a_o)}
+                rp['matching_pairs'][f'G{g}_{md}'] = e
         report['by_precision'][prec] = rp
     p0 = report['by_precision'][precisions[0]]
     report['detection'] = p0['detection']
@@ -313,8 +360,12 @@ def summary(report):
                 'ar300_vs_oracle': round(d['ar300_vs_oracle'], 4), 'frac_oracle_boxes_iou90': round(d['frac_oracle_boxes_iou90'], 4),
                 'paired_box_diff_px_mean': round(d['paired_box_diff_px_mean'], 4),
                 'map_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_pt'], 3), 'map_area_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_area_pt'], 3),
-                'ar300_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_ar300_pt'], 3)}
-    out = {'images': report['n_images']}
+                'ar300_delta_pt_pseudo_gt': round(d['pseudo_gt']['delta_ar300_pt'], 3),
+                'ap50_true_gt_oracle': round(d['gt']['ap50_oracle'], 4), 'ap50_true_gt_hip': round(d['gt']['ap50_hip'], 4),
+                'map_delta_pt_true_gt': round(d['gt']['delta_pt'], 3),
+                'map_area_delta_pt_true_gt': round(100 * (d['gt']['ap50_area_hip'] - d['gt']['ap50_area_oracle']), 3),
+                'ar300_delta_pt_true_gt': round(d['gt']['delta_ar300_pt'], 3)}
+    out = {'images': report['n_images'], 'detector': report.get('detector', 'random')}
     out.update(det(report['detection']))
     for key, m in report['matching'].items():
         out[key] = {'pairs': m['pairs']['n'], 'top1_agree': None if m['pairs']['top1_agree'] is None else round(m['pairs']['top1_agree'], 4),
@@ -326,6 +377,9 @@ def summary(report):
         e = det(rp['detection'])
         for key, m in rp['matching_pairs'].items():
             e[f'pairs_top1_agree_{key}'] = None if m['top1_agree'] is None else round(m['top1_agree'], 4)
+            if 'vs_true_product' in m:
+                e[f'pipeline_top1_delta_pt_{key}'] = round(m['vs_true_product']['delta_pt'], 3)
+                e[f'pipeline_top1_acc_oracle_{key}'] = round(m['vs_true_product']['top1_acc_oracle'], 4)
         out['by_precision'][prec] = e
     return out
 
@@ -341,12 +395,14 @@ def main():
     ap.add_argument('--control-images', type=int, default=8, help='images of the bf16-emulation control (oracle/bf16_model.py)')
     ap.add_argument('--residual-gain', type=float, default=1.0, help='synthetic_gln residual_gain (conditioning of the random detector)')
     ap.add_argument('--precisions', default='bf16,fp16', help="detector storage modes to measure (first = the report's top level)")
+    ap.add_argument('--detector', default='random', choices=['random', 'fitted'],
+                    help='random = seeded random-init weights with the calibrated head; fitted = the head fitted on shelf scenes (tests/golden/fitted_head.pt)')
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     rep = run(a.images, a.image_size, tuple(int(g) for g in a.galleries.split(',')), a.detections_per_img, a.queries, a.oracle_device,
               control_images=a.control_images, residual_gain=a.residual_gain, log=lambda *x: print(*x, flush=True),
-              precisions=tuple(a.precisions.split(',')))
+              precisions=tuple(a.precisions.split(',')), detector=a.detector)
     text = json.dumps(rep, indent=1)
     print(text)
     if a.out:

@@ -228,3 +228,31 @@ def test_pipeline_results_identical_with_and_without_skipping(cuda):
     assert int(on['count'].sum()) > 0
     for k in ('boxes', 'scores', 'indices', 'embeddings', 'count'):
         assert torch.equal(on[k], off[k]), k
+
+
+def test_classify_reads_extents_off_the_crops(cuda):
+    """The reference-shaped API (production.py:57-74: f32 crops in, labels out): `Classifier.classify` finds the constant border
+    in the crops themselves (cvpce_pad_extents) -- same labels and embeddings as without skipping, and a tensor without any
+    constant border (gallery-like noise) is unaffected."""
+    from cvpce_amd import ops, production, synthetic
+    from cvpce_amd.models import classification as C
+    enc = synthetic.synthetic_macvgg(seed=1).cuda()
+    gal = synthetic.gallery_images(40, seed=3)
+    clf = production.Classifier(enc, synthetic.TensorGallery(gal), device=cuda, emb_device=cuda, batch_size=16, k=2)
+    h0, w0 = 600, 800
+    img = torch.rand(3, h0, w0, generator=torch.Generator().manual_seed(8)).cuda()
+    boxes = _boxes(45, h0, w0, seed=31).cuda()
+    crops = ops.crop_resize(img, boxes, S, mode=0)
+    ext = ops.pad_extents(crops).cpu()
+    want = ops.crop_extents(boxes, None, h0, w0, S).cpu()
+    assert bool((ext <= want).all()) and bool((ext == want).float().mean() > 0.9)      # (content that happens to equal 0.5 may shorten an extent)
+    noise = torch.rand(5, 3, S, S, generator=torch.Generator().manual_seed(1)).cuda()
+    assert ops.pad_extents(noise).cpu().tolist() == [[S, S]] * 5
+    allc = torch.cat((crops, noise))
+    on_l, on_e = clf.classify(allc, return_embedding=True)
+    C.SKIP_PADDING = False
+    try:
+        off_l, off_e = clf.classify(allc, return_embedding=True)
+    finally:
+        C.SKIP_PADDING = True
+    assert on_l == off_l and torch.equal(on_e, off_e)

@@ -40,3 +40,13 @@ for rep in range(3):
     out = pipe.run(dimgs)
     torch.cuda.synchronize(); dt = time.time() - t
 print(f'BatchedPipeline: {len(imgs) / dt:.1f} images/s')
+# the batched drop-in evaluation (PlanogramEvaluator.detect_and_classify_batch: what `cvpce eval-planograms` runs per window of 8 images);
+# images arrive as HOST tensors, like a dataset's (the upload is inside the timed region)
+clf32 = production.Classifier.from_embedding(enc, clf.embedding, clf.annotations, device=dev, emb_device=dev)      # f32 matcher: the Classifier default
+ev = production.PlanogramEvaluator(production.ProposalGenerator(det, device=dev, confidence_threshold=0.5), clf32, production.PlanogramComparator())
+for src, what in ((imgs, 'host images'), (dimgs, 'device images')):
+    for rep in range(3):
+        torch.cuda.synchronize(); t = time.time()
+        res = ev.detect_and_classify_batch(src)
+        torch.cuda.synchronize(); dt = time.time() - t
+    print(f'detect_and_classify_batch ({what}): {len(imgs) / dt:.1f} images/s ({sum(len(b) for b, _ in res)} boxes)')
