@@ -498,6 +498,19 @@ def run_pipeline(args, rank, local_rank, world, dev):
         rep = accuracy.run(n_images=4, image_size=args.image_size, galleries=(256,), dpi=dpi, queries=64, oracle_device='cpu',
                            match_dtypes=(args.match_dtype,), images_per_batch=4, precisions=precs)
         parity = accuracy.summary(rep)
+        # the same sample with the detector whose head was FITTED on shelf scenes (tests/golden/fit_head.py): it finds the products, so
+        # AP / AR300 against the TRUE boxes is non-vacuous -- north_star's "mAP within 0.1 pt" read the way the reference reports
+        # it (cvpce/proposals_eval.py:19-48), per detector precision
+        if os.path.exists(accuracy.FITTED_HEAD):
+            repf = accuracy.run(n_images=4, image_size=args.image_size, galleries=(256,), dpi=dpi, queries=64, oracle_device='cpu',
+                                match_dtypes=(args.match_dtype,), images_per_batch=4, precisions=precs, detector='fitted')
+            fs = accuracy.summary(repf)
+            parity['fitted_detector'] = {
+                'what': 'head fitted on structured shelf scenes (tests/golden/fitted_head.pt); 4 evaluation scenes, true boxes = the pasted products',
+                'true_boxes': repf['detection']['gt']['true_boxes'],
+                'by_precision': {p_: {k_: v_ for k_, v_ in e_.items() if 'true_gt' in k_ or k_.startswith('pipeline_top1') or k_ in
+                                      ('frac_oracle_boxes_iou90', 'ap50_area_vs_oracle', 'paired_box_diff_px_mean')}
+                                 for p_, e_ in fs['by_precision'].items()}}
         parity['sample'] = ('4 structured shelf images through the whole HIP pipeline vs the whole fp32 CPU oracle; top level = the detector '
                             f'precision of this run ({args.detector_precision}), by_precision = both detector modes (bf16 default, fp16 accuracy mode); '
                             '64 paired detections + 64 ground-truth crops vs a 256-product gallery; full-size figures (32 images, '

@@ -389,7 +389,7 @@ def main():
     ap.add_argument('--images', type=int, default=32)
     ap.add_argument('--image-size', type=int, default=2048)
     ap.add_argument('--galleries', default='1000,3200')
-    ap.add_argument('--queries', type=int, default=1024)
+    ap.add_argument('--queries', type=int, default=4096, help='paired detections / ground-truth crops sampled for the matching figures')
     ap.add_argument('--detections-per-img', type=int, default=200)
     ap.add_argument('--oracle-device', default='cpu', choices=['cpu', 'cuda'])
     ap.add_argument('--control-images', type=int, default=8, help='images of the bf16-emulation control (oracle/bf16_model.py)')

@@ -79,3 +79,50 @@ def test_matching_agreement(report):
     # bf16 distance GEMM vs exact-f32 distance GEMM on the same HIP embeddings: the rounding of gallery + queries to bf16
     bf, f32 = report['matching']['G256_bf16'], report['matching']['G256_f32']
     assert abs(bf['gt_boxes']['acc_hip'] - f32['gt_boxes']['acc_hip']) <= 0.011
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the north-star tolerance read against TRUE boxes.  The random-init detector above finds no product (AP50 against the
+# pasted products' boxes ~ 0.001 for every implementation), so "mAP within 0.1 pt" could only be read as agreement on a dense
+# noise score field.  tests/golden/fitted_head.pt holds a RetinaNet head FITTED on structured shelf scenes (tests/golden/
+# fit_head.py: focal + L1 loss of torchvision's RetinaNet over the frozen, seeded backbone): the oracle's AP50 against the true
+# boxes is 0.80-0.91, the score field is bimodal like a trained detector's.  Full-size figures: profiles/r04_accuracy.json.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def fitted(cuda):
+    import accuracy
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    return accuracy.run(n_images=8, image_size=1024, galleries=(256,), dpi=200, queries=96, oracle_device='cpu',
+                        match_dtypes=('bf16', 'f32'), images_per_batch=8, control_images=0, precisions=('bf16', 'fp16'), detector='fitted')
+
+
+def test_fitted_detector_map_against_true_boxes(fitted):
+    """AP50 / AP75 / AR300 of the reference's metric code (cvpce/proposals_eval.py:19-48, cvpce/metrics.py:66-73,116-138) for the
+    HIP detector and for the fp32 oracle, both against the pasted products' true boxes: |delta| <= 0.1 pt in the fp16 accuracy
+    mode (north_star's tolerance); the default bf16 storage is within half a point (measured +0.21 / -0.19 / 0.0 pt here,
+    +0.01 / +0.14 / +0.03 pt on the 32 full-size scenes)."""
+    b, f = fitted['by_precision']['bf16']['detection'], fitted['by_precision']['fp16']['detection']
+    g = f['gt']
+    assert g['true_boxes'] >= 200 and g['ap50_oracle'] >= 0.7 and g['ar300_oracle'] >= 0.9, g      # non-vacuous: the detector finds the products
+    assert abs(g['delta_pt']) <= 0.1 and abs(g['delta75_pt']) <= 0.1 and abs(g['delta_ar300_pt']) <= 0.1, g
+    assert abs(100 * (g['ap50_area_hip'] - g['ap50_area_oracle'])) <= 0.1, g
+    gb = b['gt']
+    assert abs(gb['delta_pt']) <= 0.5 and abs(gb['delta75_pt']) <= 0.5 and abs(gb['delta_ar300_pt']) <= 0.5, gb
+    # agreement with the oracle's own detections: a structured score field has no dense near-ties for 16-bit storage to flip
+    assert f['frac_oracle_boxes_iou90'] >= 0.99 and f['paired_box_diff_px_mean'] < 0.1, f
+    assert b['frac_oracle_boxes_iou90'] >= 0.93 and b['paired_box_diff_px_mean'] < 0.6, b
+    assert abs(f['confident_hip'] - f['confident_oracle']) <= 2 and abs(b['confident_hip'] - b['confident_oracle']) <= 4
+
+
+def test_fitted_pipeline_top1_against_true_products(fitted):
+    """End to end: own box -> own crop -> own embedding -> own nearest neighbour, against the id of the pasted product under the
+    detection, HIP pipeline vs fp32 oracle path.  ~70 samples here (one flip = 1.5 pt): at most one flip apart; the full-size
+    report resolves it (861-879 samples: +0.0 ... +0.34 pt)."""
+    for prec in ('bf16', 'fp16'):
+        for key, m in fitted['by_precision'][prec]['matching_pairs'].items():
+            v = m['vs_true_product']
+            assert v['n'] >= 50 and v['top1_acc_oracle'] >= 0.6, (prec, key, v)
+            assert abs(v['delta_pt']) <= 100.0 / v['n'] + 1e-6, (prec, key, v)
+            assert m['top1_agree'] >= (0.93 if prec == 'fp16' else 0.9), (prec, key, m)
+    for key, m in fitted['matching'].items():                          # the true boxes cropped and matched by both paths
+        assert abs(m['gt_boxes']['delta_pt']) <= 1.1 and m['gt_boxes']['top1_agree'] >= 0.98, (key, m['gt_boxes'])
