@@ -10,7 +10,7 @@ R=$PWD; O=$R/gpurun_out; B=$R/bench.py
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $B --steps 5 --warmup 2 > $O/prof_$tag.log 2>&1
 echo "stats pass done"
-Q="--steps 1 --warmup 1 --windows 1 --no-roofline --no-cpu-baseline --no-parity --no-h2d --no-peaks --no-workloads"
+Q="--steps 1 --warmup 1 --windows 1 --no-roofline --no-cpu-baseline --no-parity --no-h2d --no-peaks --no-workloads --no-precision-leg"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_$tag/fetch -- python3 $B $Q > /dev/null 2>&1
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_$tag/write -- python3 $B $Q > /dev/null 2>&1
