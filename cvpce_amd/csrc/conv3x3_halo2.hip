@@ -29,6 +29,12 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define CVPCE_DBG 0
 #endif
 
+#ifndef G2_LIST_DEEP_WEIGHTS
+#define G2_LIST_DEEP_WEIGHTS 0     // 1: work-list launches prefetch the weight fragments TWO steps ahead (3 slots, 246-256 VGPRs, no spill).
+                                   // Measured with the row cut on, same call, three alternations: 27.92 / 27.92 / 27.97 ms (one step ahead)
+                                   // vs 27.95 / 27.98 / 28.12 ms per 1 600 crops -- the cut tiles are bound by the weight stream's BYTES
+                                   // (conv4_2 without any weight load: 3.99 -> 2.85 ms with the cut; with: 4.81 -> 4.33), not by its latency
+#endif
 #define G2_T 16
 #define G2_P 18
 #define G2_NPIX 324
@@ -98,15 +104,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 
     const int nchunks = a.Cin >> 6;
     const int lbid = (CVPCE_DBG & 2) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    int ntiles_ = a.ntiles;
-    if constexpr (LIST) ntiles_ = __builtin_amdgcn_readfirstlane(*a.list_count) * a.ctiles;     // <= a.ntiles (checked by the list builder)
-    const int my_tiles = (ntiles_ - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Which tiles this workgroup computes.  Plain launches: tile lbid, lbid + grid, ... (all tiles cost the same).  LIST launches:
+    // a CONTIGUOUS block of the list per workgroup -- listed tiles differ in cost when they are cut at `rows`, and the list is
+    // crop-major with a fixed number of tiles per crop, so a stride that is a multiple of it would hand one workgroup nothing but
+    // bottom-row (cut) tiles and another nothing but full ones.  The cout tile stays fixed per workgroup (lbid % ctiles: one
+    // weight set per workgroup, and with an even grid per XCD), its group's workgroups split the list entries among them.
+    int my_tiles, l_first = 0;
+    if constexpr (LIST) {
+        const int entries = __builtin_amdgcn_readfirstlane(*a.list_count);      // <= a.ptiles (checked by the list builder)
+        const int groups = (int)gridDim.x / a.ctiles;                          // workgroups per cout tile (the host launches grid % ctiles == 0)
+        const int per = (entries + groups - 1) / groups;
+        l_first = (lbid / a.ctiles) * per;
+        my_tiles = entries - l_first < per ? entries - l_first : per;
+    } else {
+        my_tiles = (a.ntiles - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    }
     if (my_tiles <= 0) return;
     const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
     unsigned long long* llist = reinterpret_cast<unsigned long long*>(smem + G2_LLIST_OFF);
     if constexpr (LIST) {
         const int staged = my_tiles < G2_MAX_SEQ ? my_tiles : G2_MAX_SEQ;
-        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[(lbid + idx * (int)gridDim.x) / a.ctiles];
+        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[l_first + idx];
         __syncthreads();
     }
 
@@ -145,11 +163,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 
     // tile seq -> (image, tile row, tile column, cout tile); cout tile fastest.  ext (LIST): the crop's extents on the INPUT tensor
     auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct, int& ext) {
-        const int t = lbid + seq * (int)gridDim.x;
-        ct = t % a.ctiles;
-        const int p = t / a.ctiles;
         if constexpr (LIST) {
-            const unsigned long long e = seq < G2_MAX_SEQ ? llist[seq] : a.list[p];
+            ct = lbid % a.ctiles;
+            const unsigned long long e = seq < G2_MAX_SEQ ? llist[seq] : a.list[l_first + seq];
             const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
             ext = __builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
             n = lo >> 16;
@@ -158,6 +174,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
             return;
         }
         ext = 0;
+        const int t = lbid + seq * (int)gridDim.x;
+        ct = t % a.ctiles;
+        const int p = t / a.ctiles;
         n = p / a.tiles_per_image;
         const int r = p - n * a.tiles_per_image;
         if (a.mask) {
@@ -250,7 +269,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
             for (int j = 0; j < NB; ++j) acc[i][j] = b0[i];
     }
 
-    bf16x8 af[2][3][2];       // [step parity][kh][16-cout block]
+    // weight slots: the next step's fragments are fetched while this one computes (2 slots); G2_LIST_DEEP_WEIGHTS = 1 makes it two
+    // steps ahead for work-list launches (3 slots) -- built, measured, not faster (see the macro)
+    constexpr int NA = (LIST && G2_LIST_DEEP_WEIGHTS) ? 3 : 2;
+    bf16x8 af[NA][3][2];      // [step % NA][kh][16-cout block]
     bf16x8 bfr[4];            // patch-row ring
     unsigned e0, e1;          // fragment base addresses of the step being fetched (even / odd patch rows)
 
@@ -260,8 +282,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + (kh_ * 3 + ((T) >> 1)) * 128 + ((T) & 1) * 64, 0); \
-                af[(T) & 1][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);                                        \
+                af[(T) % NA][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);                                       \
             }                                                                                                  \
+    }
+    // at the start of step T: the weights of the step NA - 1 ahead (steps 6, 7 = steps 0, 1 of the next chunk)
+#define G2_PREFETCH_A(T)                                                                                       \
+    if constexpr (NA == 2) {                                                                                   \
+        if constexpr ((T) < 5) { G2_LOAD_A((T) + 1, sb_cur) } else { G2_LOAD_A(0, sb_next) }                   \
+    } else {                                                                                                   \
+        if constexpr ((T) < 4) { G2_LOAD_A((T) + 2, sb_cur) } else { G2_LOAD_A((T) - 4, sb_next) }             \
     }
 #define G2_SET_E(T, BUFB)                                                                                      \
     {                                                                                                          \
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
                 _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                            \
-                    acc[mt_][(P) - kh_] = E::mfma16(af[(T) & 1][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_]); \
+                    acc[mt_][(P) - kh_] = E::mfma16(af[(T) % NA][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_]); \
             }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // step T < 5: fetch the next step's weights, stream the rows; rows 16, 17 prefetch rows 0, 1 of step T + 1
 #define G2_STEP(T)                                                                                             \
     {                                                                                                          \
-        G2_LOAD_A((T) + 1, sb_cur)                                                                             \
+        G2_PREFETCH_A(T)                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         G2_ROWS_AND_TAIL(T, (T) + 1, bufb, )                                                                   \
     }
@@ -340,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
+        if constexpr (LIST) return t_ct;                 // (fixed per workgroup)
         if (seq + 1 < my_tiles) return (lbid + (seq + 1) * (int)gridDim.x) % a.ctiles;
         return t_ct;                                    // no next chunk: any valid address will do
     };
@@ -356,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 af[0][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);
                 if (dbg8_) af[1][kh_][mt_] = af[0][kh_][mt_];
             }
+        if constexpr (NA == 3) { G2_LOAD_A(1, sb_cur) }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -375,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         G2_STEP(0) G2_STEP(1) G2_STEP(2) G2_STEP(3) G2_STEP(4)
         // ---- last step of the chunk, with the chunk hand-off before its rows 16, 17 prefetch from the NEXT buffer ----
         {
-            G2_LOAD_A(0, sb_next)        // step 0 of the next chunk (slot 0); past the last chunk a harmless reload
+            G2_PREFETCH_A(5)             // step 0 (NA = 3: step 1) of the next chunk; past the last chunk a harmless reload
             __builtin_amdgcn_sched_barrier(0);
             // After the last chunk the barrier, the reads and the weight loads still run -- on valid, unused data -- so
             // that the loop body has one shape and the accumulators stay in place.
@@ -517,6 +548,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #undef G2_ROW
 #undef G2_READ
 #undef G2_SET_E
+#undef G2_PREFETCH_A
 #undef G2_LOAD_A
 }
 
@@ -527,7 +559,8 @@ static int launch_halo2(Halo2Args a, hipStream_t stream) {
     const int smem = a.mask ? G2_SMEM_MASKED : (LIST ? G2_SMEM_LIST : 3 * G2_A_BYTES);
     if (!cvpce_smem_attr_done<conv3x3_halo2_kernel<E, POOL, GMAX, LIST>>((const void*)conv3x3_halo2_kernel<E, POOL, GMAX, LIST>, G2_SMEM_MASKED))
         return CVPCE_ERR_LAUNCH;
-    const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
+    int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
+    if (LIST) grid = grid < a.ctiles ? a.ctiles : grid / a.ctiles * a.ctiles;     // (work-list launches: the same number of workgroups per cout tile)
     if (a.mask && (a.ntiles + grid - 1) / grid > G2_MAX_SEQ) return CVPCE_ERR_ARG;   // the workgroup's tile list lives in LDS
     hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX, LIST>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();

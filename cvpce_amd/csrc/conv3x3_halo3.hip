@@ -90,25 +90,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // fetched again from beyond it: conv2_1 +2.3 %, conv2_2 +1.8 % (same call, three alternations, real activations;
     // CVPCE_DBG & 2 = the plain order, dev A/B)
     const int lbid = (CVPCE_DBG & 2) ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    int ntiles_ = a.ntiles;
-    if constexpr (LIST) ntiles_ = __builtin_amdgcn_readfirstlane(*a.list_count) * a.ctiles;
-    const int my_tiles = (ntiles_ - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    // LIST launches: a contiguous block of the list per workgroup, the cout tile fixed per workgroup (see conv3x3_halo2.hip)
+    int my_tiles, l_first = 0;
+    if constexpr (LIST) {
+        const int entries = __builtin_amdgcn_readfirstlane(*a.list_count);
+        const int groups = (int)gridDim.x / a.ctiles;
+        const int per = (entries + groups - 1) / groups;
+        l_first = (lbid / a.ctiles) * per;
+        my_tiles = entries - l_first < per ? entries - l_first : per;
+    } else {
+        my_tiles = (a.ntiles - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
+    }
     if (my_tiles <= 0) return;
     const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
     const int total_sub = 2 * total_chunks;
     unsigned long long* llist = reinterpret_cast<unsigned long long*>(smem + G3_LLIST_OFF);
     if constexpr (LIST) {
         const int staged = my_tiles < G3_MAX_SEQ ? my_tiles : G3_MAX_SEQ;
-        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[(lbid + idx * (int)gridDim.x) / a.ctiles];
+        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[l_first + idx];
         __syncthreads();
     }
 
     auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct, int& ext) {
-        const int t = lbid + seq * (int)gridDim.x;
-        ct = t % a.ctiles;
-        const int p = t / a.ctiles;
         if constexpr (LIST) {
-            const unsigned long long e = seq < G3_MAX_SEQ ? llist[seq] : a.list[p];
+            ct = lbid % a.ctiles;
+            const unsigned long long e = seq < G3_MAX_SEQ ? llist[seq] : a.list[l_first + seq];
             const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
             ext = __builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
             n = lo >> 16;
@@ -117,6 +123,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
             return;
         }
         ext = 0;
+        const int t = lbid + seq * (int)gridDim.x;
+        ct = t % a.ctiles;
+        const int p = t / a.ctiles;
         n = p / (a.tiles_x * a.tiles_y);
         const int r = p - n * (a.tiles_x * a.tiles_y);
         ty = r / a.tiles_x;
@@ -293,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
+        if constexpr (LIST) return t_ct;                 // (fixed per workgroup)
         if (seq + 1 < my_tiles) return (lbid + (seq + 1) * (int)gridDim.x) % a.ctiles;
         return t_ct;                                    // no next chunk: any valid address will do
     };
@@ -423,7 +433,8 @@ static int launch_halo3(Halo3Args a, hipStream_t stream) {
     a.ntiles = a.ptiles * a.ctiles;
     const int smem = LIST ? G3_SMEM_LIST : 3 * G3_A_BYTES;
     if (!cvpce_smem_attr_done<conv3x3_halo3_kernel<E, POOL, LIST>>((const void*)conv3x3_halo3_kernel<E, POOL, LIST>, smem)) return CVPCE_ERR_LAUNCH;
-    const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
+    int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
+    if (LIST) grid = grid < a.ctiles ? a.ctiles : grid / a.ctiles * a.ctiles;     // (work-list launches: the same number of workgroups per cout tile)
     hipLaunchKernelGGL((conv3x3_halo3_kernel<E, POOL, LIST>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }

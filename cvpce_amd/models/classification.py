@@ -37,11 +37,11 @@ FUSED_EMBED_BATCH = min(FUSED_EMBED_BATCH, FUSED_EMBED_MAX)        # (an over-la
 # with 0.5, so the part of the 256 x 256 embedder input below / right of the box content is the same constant in every crop; conv
 # tiles whose receptive field lies inside it are not computed (bit-identical results: tests/test_gpu_skip.py).  A/B switch.
 SKIP_PADDING = _os.environ.get('CVPCE_SKIP_PADDING', '1') != '0'
-# Cutting the LISTED tiles at their last non-constant row as well (the halo kernels stop streaming patch rows there) is built and
-# bit-exact (tests/test_gpu_skip.py runs both settings) but OFF: same-box A/B 31.16 vs 31.10 ms per 1 600 bench-shaped crops.  A cut tile
-# issues a third of the MFMAs per step against the same weight stream, and its steps become too short to hide the weight loads'
-# latency (conv4_2: 5.01 -> 4.77 ms at a third fewer MFMAs) -- profiles/r04_rejected_experiments.md.
-SKIP_ROWS = _os.environ.get('CVPCE_SKIP_ROWS', '0') != '0'
+# ... and the LISTED tiles are cut at their last non-constant row (list entries carry `rows` in {4, 8, 12, 16}; the halo kernels stop
+# streaming patch rows there).  Pays since the work-list kernels take CONTIGUOUS blocks of the list (with the old strided
+# assignment a workgroup got nothing but cut tiles or nothing but full ones): same call, 29.15 / 29.41 -> 27.98 ms per 1 600
+# bench-shaped crops.  A/B switch; tests/test_gpu_skip.py runs both settings.
+SKIP_ROWS = _os.environ.get('CVPCE_SKIP_ROWS', '1') != '0'
 
 
 def _passes(n, step, longest):

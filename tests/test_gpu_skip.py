@@ -104,7 +104,7 @@ def _extent(e0, pool_mask, nops, size):
 
 @pytest.fixture(params=[False, True], ids=['tiles', 'tiles+rows'])
 def skip_rows(request):
-    """Both settings of the row-level cut (classification.SKIP_ROWS; off by default: measured no faster)."""
+    """Both settings of the row-level cut (classification.SKIP_ROWS: tiles only | tiles cut at their last non-constant row)."""
     from cvpce_amd.models import classification as C
     old, C.SKIP_ROWS = C.SKIP_ROWS, request.param
     yield request.param
