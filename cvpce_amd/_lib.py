@@ -51,7 +51,8 @@ SIGNATURES = {
     'cvpce_pack_embed_input': (c_int, [_fp, _vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_crop_extents': (c_int, [_fp, _ip, c_int, c_int, c_int, c_int, _ip, _vp]),
     'cvpce_pad_extents': (c_int, [_fp, c_int, c_int, c_float, _ip, _vp]),
-    'cvpce_embed_worklists': (c_int, [_ip, c_int, c_int, ctypes.c_uint, _vp, c_int, _vp, c_longlong, _ip, _vp]),
+    'cvpce_embed_worklists': (c_int, [_ip, c_int, c_int, ctypes.c_uint, _vp, c_int, _vp, c_longlong, _ip, _ip, _vp]),
+    'cvpce_mac_init': (c_int, [_fp, c_int, c_int, c_int, c_int, _fp, _fp, c_int, c_int, _ip, _vp]),
     'cvpce_vgg_stem_fused_list': (c_int, [_vp, c_int, _vp, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp, _ip, _vp]),
     'cvpce_conv3x3_halo_list': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 9 + [_vp, _ip, _vp]),
     'cvpce_detect_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

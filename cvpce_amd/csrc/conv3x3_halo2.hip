@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 if (tx * G2_T + col < a.W) {
 #pragma unroll
                     for (int nt = 0; nt < NB; ++nt)
-                        if (ty * G2_T + nt < a.H) {
+                        if (ty * G2_T + nt < a.H && (!LIST || nt < rows_t)) {      // (LIST: the rows this tile computed; the rest is cvpce_mac_init's)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 m[j] = max(m[j], __float_as_uint(relu_bits(acc[0][nt][j])));

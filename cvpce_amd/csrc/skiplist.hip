@@ -30,6 +30,8 @@ struct WorklistArgs {
     unsigned long long* lists;       // [nl][stride]
     long long stride;
     int* counts;                     // [2 * nl]: tiles listed per layer, then sixteenths of a tile's MFMA work actually performed per layer
+    int* computed;                   // optional [nl][n][2]: per crop, the conv-output rows a layer computes (rows below are left to the
+                                     // constant crop) and its listed tile columns -- what cvpce_mac_init needs
 };
 
 __device__ __forceinline__ int skl_extent(int e0, int S, unsigned pool_mask, int nops, int size) {
@@ -75,6 +77,18 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
             s_cnt[tid] += v;
             __syncthreads();
         }
+        if (a.computed && n < a.n && blockIdx.y == 0) {
+            // rows [0, rc) of the conv output (before a fused pool) are computed for this crop: whole tile rows, the last one cut
+            int rc = ny * 16;
+            if (L.skip >= 2 && ny > 0) {
+                const int left = eoy_ - (ny - 1) * L.tile_h;
+                const int act = left < L.tile_h ? left : L.tile_h;
+                int rows = ((act * 16 + L.tile_h - 1) / L.tile_h + 3) & ~3;
+                rc = (ny - 1) * 16 + (rows > 16 ? 16 : rows);
+            }
+            a.computed[((long long)blockIdx.x * a.n + n) * 2] = rc;
+            a.computed[((long long)blockIdx.x * a.n + n) * 2 + 1] = nx;
+        }
         const int base = s_base + s_cnt[tid] - cnt;
         const int chunk_total = s_cnt[1023];
         __syncthreads();
@@ -106,12 +120,12 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
 }
 
 extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsigned pool_mask, const cvpce_skip_layer* layers, int n_layers,
-                                     unsigned long long* lists, long long list_stride, int* counts, void* stream) {
+                                     unsigned long long* lists, long long list_stride, int* counts, int* computed, void* stream) {
     if (n_layers <= 0) return CVPCE_OK;
     if (!ext0 && n_images > 1) return CVPCE_ERR_ARG;
     if (!layers || !lists || !counts || n_layers > SKL_MAX_LAYERS || n_images <= 0 || n_images > 65535 || S <= 0 || S > 32767) return CVPCE_ERR_ARG;
     WorklistArgs a;
-    a.ext0 = ext0; a.n = n_images; a.S = S; a.nl = n_layers; a.pool_mask = pool_mask; a.lists = lists; a.stride = list_stride; a.counts = counts;
+    a.ext0 = ext0; a.n = n_images; a.S = S; a.nl = n_layers; a.pool_mask = pool_mask; a.lists = lists; a.stride = list_stride; a.counts = counts; a.computed = computed;
     for (int i = 0; i < n_layers; ++i) {
         const cvpce_skip_layer& l = layers[i];
         if (l.H <= 0 || l.W <= 0 || l.tile_h <= 0 || l.tile_w <= 0 || l.in_H <= 0 || l.in_W <= 0 || l.in_H > 4095 || l.in_W > 4095) return CVPCE_ERR_ARG;
@@ -123,5 +137,30 @@ extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsig
     const int split = n_images >= 64 ? 8 : 1;
     if (hipMemsetAsync(counts + n_layers, 0, sizeof(int) * n_layers, (hipStream_t)stream) != hipSuccess) return CVPCE_ERR_LAUNCH;
     hipLaunchKernelGGL(embed_worklists_kernel, dim3(n_layers, split), dim3(1024), 0, (hipStream_t)stream, a);
+    return cvpce_check_launch();
+}
+
+
+// MAC descriptor start values for the layers whose maximum (classification.py:46-49) ranges over tiles / rows the work lists leave
+// out: what is left out is constant, i.e. the constant crop's own map there, whose row / column suffix maxima the host tabulated once
+// (rtab[r][c] = max over rows >= r, ctab[x][c] = max over columns >= x; both end with a zero row).  desc[n][off + c] starts at
+// max(rtab[rows computed for crop n][c], ctab[16 * tile columns listed for crop n][c]); the conv kernel's atomic maxima do the rest.
+__global__ void mac_init_kernel(float* __restrict__ desc, int stride, int off, int C, const float* __restrict__ rtab, const float* __restrict__ ctab,
+                                int Hc, int Wc, const int* __restrict__ computed) {
+    const int n = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int rc = computed[2 * n], cc = computed[2 * n + 1] * 16;
+    rc = rc < Hc ? rc : Hc;
+    cc = cc < Wc ? cc : Wc;
+    desc[(size_t)n * stride + off + c] = fmaxf(rtab[(size_t)rc * C + c], ctab[(size_t)cc * C + c]);
+}
+
+extern "C" int cvpce_mac_init(float* desc, int n_images, int desc_stride, int desc_off, int C, const float* row_suffix_max,
+                              const float* col_suffix_max, int Hc, int Wc, const int* computed, void* stream) {
+    if (n_images <= 0) return CVPCE_OK;
+    if (!desc || !row_suffix_max || !col_suffix_max || !computed || C <= 0 || Hc <= 0 || Wc <= 0 || desc_off < 0 || desc_off + C > desc_stride || n_images > 65535)
+        return CVPCE_ERR_ARG;
+    hipLaunchKernelGGL(mac_init_kernel, dim3((C + 255) / 256, n_images), dim3(256), 0, (hipStream_t)stream, desc, desc_stride, desc_off, C,
+                       row_suffix_max, col_suffix_max, Hc, Wc, computed);
     return cvpce_check_launch();
 }

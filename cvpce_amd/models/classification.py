@@ -42,6 +42,10 @@ SKIP_PADDING = _os.environ.get('CVPCE_SKIP_PADDING', '1') != '0'
 # assignment a workgroup got nothing but cut tiles or nothing but full ones): same call, 29.15 / 29.41 -> 27.98 ms per 1 600
 # bench-shaped crops.  A/B switch; tests/test_gpu_skip.py runs both settings.
 SKIP_ROWS = _os.environ.get('CVPCE_SKIP_ROWS', '1') != '0'
+# ... and the two layers that carry the MAC maximum (conv4_3, conv5_3; classification.py:46-49) skip like the others: what their lists
+# leave out is the constant crop's own map there, whose row / column suffix maxima are tabulated once per engine and start the
+# descriptor (`cvpce_mac_init`) before the kernels take their atomic maxima over what they do compute.  A/B switch.
+SKIP_MAC = _os.environ.get('CVPCE_SKIP_MAC', '1') != '0'
 
 
 def _passes(n, step, longest):
@@ -112,6 +116,7 @@ class MACVGGEngine:
         self.device = device
         self.embedding_size = model.embedding_size
         self._skip_plans = {}      # input size -> the work-list schedule of `_embed_pass_skip` (None: this plan has no such schedule)
+        self._mac_tables = {}      # id of a constant crop -> per MAC layer, the row / column suffix maxima of the constant crop's map
         self._const_crops = {}     # (mean, std, channels, size) -> the all-padding crop
 
     # ---- constant-padding tile skipping --------------------------------------------------------------------------------------
@@ -120,7 +125,7 @@ class MACVGGEngine:
         per step, pool_mask), or None when this engine's plan is not stem + 3x3 halo convolutions with the MAC descriptors fused
         (then nothing is skipped).  Extent bookkeeping (include/cvpce_amd.h `cvpce_skip_layer`): the pass is a chain of ops on
         the crop -- conv (+1) and pool (halve upwards) -- and every tensor is named by the number of ops before it."""
-        key = (size, SKIP_ROWS)
+        key = (size, SKIP_ROWS, SKIP_MAC)
         if key in self._skip_plans:
             return self._skip_plans[key]
         steps, layers, chain = None, [], []
@@ -149,7 +154,7 @@ class MACVGGEngine:
                     th, tw, oh = th // 2, tw // 2, h // 2
                 if not store:
                     oh, th, tw = h, 16, 16
-                layers.append(ops.skip_layer(oh, oh, th, tw, len(chain), h, h, in_ops, 0 if mac else (2 if SKIP_ROWS else 1)))
+                layers.append(ops.skip_layer(oh, oh, th, tw, len(chain), h, h, in_ops, 0 if (mac and not SKIP_MAC) else (2 if SKIP_ROWS else 1)))
                 steps.append(('conv', pc, pool, mac, store))
                 i += (3 if pool else 2) if mac else 1
                 if not mac and i < len(plan) and plan[i][0] != 'conv' and plan[i][0] != 'conv_pool':
@@ -174,12 +179,50 @@ class MACVGGEngine:
             self._const_crops[key] = ops.crop_resize(img, box, size, mode=2 if channels == 4 else 1, mean=mean, std=std)[0].contiguous()
         return self._const_crops[key]
 
+    def mac_tables(self, const_in, sched):
+        """Per MAC layer of the schedule: (row suffix maxima (H + 1, C), column suffix maxima (W + 1, C)) f32 of the CONSTANT crop's
+        post-ReLU map at that layer -- entry r = the maximum over rows >= r (all columns), the last entry 0.  The constant crop goes
+        through the plain kernels once (same arithmetic per pixel as the work-list instances); a crop's descriptor starts from the
+        entry at the first row / column its list leaves out."""
+        key = (const_in.data_ptr(), id(sched))
+        if key in self._mac_tables:
+            return self._mac_tables[key]
+        steps = sched[0]
+        t = ops.vgg_stem(const_in[None].contiguous(), self.stem)
+        tables = {}
+        for li, (kind, pc, pool, mac, store) in enumerate(steps[1:], start=1):
+            if not mac:
+                t = ops.conv2d(t, pc, act=1, pool=pool)
+                continue
+            full = ops.conv2d(t, pc, act=1)                               # the map the MAC epilogue takes its maximum over
+            m = full[0].to(torch.float32)                                 # (H, W, C), values >= 0
+            zero = torch.zeros((1, m.shape[2]), dtype=torch.float32, device=m.device)
+            rows = torch.cat((torch.cummax(m.amax(dim=1).flip(0), 0).values.flip(0), zero)).contiguous()
+            cols = torch.cat((torch.cummax(m.amax(dim=0).flip(0), 0).values.flip(0), zero)).contiguous()
+            tables[li] = (rows, cols)
+            if store:
+                t = ops.maxpool2d(full, 2, 2) if pool else full
+        self._mac_tables[key] = tables
+        self._keep_const = getattr(self, '_keep_const', []) + [const_in]  # (the key holds a data pointer: keep the tensor alive)
+        return tables
+
     def _embed_pass_skip(self, xb, ext, const_in, sched):
         """One pass of the schedule over work lists: xb (n,S,S,c) + the constant crop as image n -> MAC descriptor (n,1024)."""
         steps, layers, pool_mask = sched
         n = xb.shape[0]
-        lists, counts = ops.embed_worklists(ext, n + 1, xb.shape[1], pool_mask, layers, (xb.shape[1] // 16) ** 2)
-        desc = torch.zeros((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
+        mac_skips = any(st[3] and layers[i][-1] for i, st in enumerate(steps) if i)      # a MAC layer whose list leaves tiles / rows out
+        if mac_skips:
+            lists, counts, computed = ops.embed_worklists(ext, n + 1, xb.shape[1], pool_mask, layers, (xb.shape[1] // 16) ** 2, want_computed=True)
+            tables = self.mac_tables(const_in, sched)
+            desc = torch.empty((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
+            o = 0
+            for li, st in enumerate(steps):
+                if li and st[3]:
+                    ops.mac_init(desc, o, tables[li][0], tables[li][1], computed[li])
+                    o += st[1].cout
+        else:
+            lists, counts = ops.embed_worklists(ext, n + 1, xb.shape[1], pool_mask, layers, (xb.shape[1] // 16) ** 2)
+            desc = torch.zeros((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
         off = 0
         t = ops.vgg_stem_list(xb, const_in, self.stem, lists[0], counts[0:1])
         for li, (kind, pc, pool, mac, store) in enumerate(steps[1:], start=1):

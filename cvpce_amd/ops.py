@@ -401,16 +401,24 @@ def skip_layer(h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip):
     return [int(v) for v in (h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip)]
 
 
-def embed_worklists(ext0, n_images, size, pool_mask, layers, max_tiles):
+def embed_worklists(ext0, n_images, size, pool_mask, layers, max_tiles, want_computed=False):
     """ext0 (n_images - 1, 2) int32 (the last image is the implied constant crop); pool_mask: the pass's op chain (bit i: op i is
     a 2x2 pool, else a 3x3 conv); layers: list of `skip_layer` -> (lists (L, n_images * max_tiles) int64, counts (2 L,) int32:
-    tiles per layer, then the layers' MFMA work in sixteenths of a tile), all on the device, no synchronisation."""
+    tiles per layer, then the layers' MFMA work in sixteenths of a tile [, computed (L, n_images, 2) int32: conv rows computed /
+    tile columns listed per crop]), all on the device, no synchronisation."""
     _need_cuda(ext0)
     dev = ext0.device if ext0 is not None else torch.device('cuda', torch.cuda.current_device())
     lists = torch.empty((len(layers), n_images * max_tiles), dtype=torch.int64, device=dev)
     counts = torch.empty((2 * len(layers),), dtype=torch.int32, device=dev)
-    T.embed_worklists(ext0, int(n_images), int(size), int(pool_mask), [v for l in layers for v in l], lists, counts)
-    return lists, counts
+    computed = torch.empty((len(layers), n_images, 2), dtype=torch.int32, device=dev) if want_computed else None
+    T.embed_worklists(ext0, int(n_images), int(size), int(pool_mask), [v for l in layers for v in l], lists, counts, computed)
+    return (lists, counts, computed) if want_computed else (lists, counts)
+
+
+def mac_init(desc, off, row_suffix_max, col_suffix_max, computed):
+    """desc[:, off:off+C] = what the work list of a MAC layer leaves to the constant crop (see include/cvpce_amd.h cvpce_mac_init)."""
+    _need_cuda(desc, row_suffix_max, col_suffix_max, computed)
+    T.mac_init(desc, int(off), row_suffix_max, col_suffix_max, computed)
 
 
 def vgg_stem_list(x, const_in, ps, work, count, units=None):

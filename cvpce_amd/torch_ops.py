@@ -188,8 +188,21 @@ def _pad_extents(images, pad, ext):
     check(lib.cvpce_pad_extents(_p(images), images.shape[0], images.shape[2], pad, _p(ext), _stream()), 'cvpce_pad_extents')
 
 
-@_op('embed_worklists(Tensor? ext0, int n_images, int size, int pool_mask, int[] layers, Tensor(a!) lists, Tensor(b!) counts) -> ()')
-def _embed_worklists(ext0, n_images, size, pool_mask, layers, lists, counts):
+@_op('mac_init(Tensor(a!) desc, int off, Tensor row_suffix_max, Tensor col_suffix_max, Tensor computed) -> ()')
+def _mac_init(desc, off, row_suffix_max, col_suffix_max, computed):
+    """desc (N, D) f32; tables (H + 1, C) / (W + 1, C) f32; computed (N, 2) int32 = one layer's slice of embed_worklists' `computed`."""
+    c = row_suffix_max.shape[1]
+    if desc.dtype != torch.float32 or not desc.is_contiguous() or row_suffix_max.dtype != torch.float32 or col_suffix_max.dtype != torch.float32 \
+            or not row_suffix_max.is_contiguous() or not col_suffix_max.is_contiguous() or col_suffix_max.shape[1] != c \
+            or computed.dtype != torch.int32 or not computed.is_contiguous() or computed.numel() < 2 * desc.shape[0]:
+        raise RuntimeError('mac_init: bad argument shapes / types')
+    check(lib.cvpce_mac_init(_p(desc), desc.shape[0], desc.shape[1], off, c, _p(row_suffix_max), _p(col_suffix_max), row_suffix_max.shape[0] - 1,
+                             col_suffix_max.shape[0] - 1, _p(computed), _stream()), 'cvpce_mac_init')
+
+
+@_op('embed_worklists(Tensor? ext0, int n_images, int size, int pool_mask, int[] layers, Tensor(a!) lists, Tensor(b!) counts, '
+     'Tensor(c!)? computed) -> ()')
+def _embed_worklists(ext0, n_images, size, pool_mask, layers, lists, counts, computed):
     """layers: 9 ints per layer in the field order of `cvpce_skip_layer`; lists (n_layers, stride) int64; counts (2 * n_layers,) int32 (tiles, then row units)."""
     nf = len(_lib.SkipLayer._fields_)
     nl = len(layers) // nf
@@ -197,8 +210,10 @@ def _embed_worklists(ext0, n_images, size, pool_mask, layers, lists, counts):
             or counts.numel() != 2 * nl or (ext0 is not None and (ext0.dtype != torch.int32 or not ext0.is_contiguous() or ext0.numel() < 2 * (n_images - 1))):
         raise RuntimeError('embed_worklists: bad argument shapes / types')
     arr = (_lib.SkipLayer * nl)(*[_lib.SkipLayer(*[int(v) for v in layers[i * nf:(i + 1) * nf]]) for i in range(nl)])
-    check(lib.cvpce_embed_worklists(_p(ext0), n_images, size, pool_mask, ctypes.cast(arr, ctypes.c_void_p), nl, _p(lists), lists.shape[1], _p(counts), _stream()),
-          'cvpce_embed_worklists')
+    if computed is not None and (computed.dtype != torch.int32 or not computed.is_contiguous() or computed.numel() < 2 * nl * n_images):
+        raise RuntimeError('embed_worklists: computed must be a contiguous int32 tensor of (n_layers, n_images, 2)')
+    check(lib.cvpce_embed_worklists(_p(ext0), n_images, size, pool_mask, ctypes.cast(arr, ctypes.c_void_p), nl, _p(lists), lists.shape[1], _p(counts),
+                                    _p(computed), _stream()), 'cvpce_embed_worklists')
 
 
 @_op('vgg_stem_fused_list(Tensor x, Tensor const_in, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out, Tensor work, Tensor count) -> ()')

@@ -194,9 +194,17 @@ typedef struct {
  * wholly constant, rounded up to 4 -- the halo kernels compute only those, the rest of the tile is neither computed nor stored)
  * list_stride >= n_images * tiles of the largest layer.  No host synchronisation: the kernels read counts[l] themselves.
  * counts has 2 * n_layers entries: counts[n_layers + l] = the MFMA work layer l performs, in sixteenths of a full tile (a tile cut
- * at `rows` < 16 streams rows + 1 of its 16 row groups) -- what `roofline` counts as executed FLOPs. */
+ * at `rows` < 16 streams rows + 1 of its 16 row groups) -- what `roofline` counts as executed FLOPs.
+ * computed (optional, [n_layers][n_images][2]): per layer and crop, (conv-output rows computed, tile columns listed) -- the region
+ * cvpce_mac_init has to cover from the constant crop. */
 int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsigned pool_mask, const cvpce_skip_layer* layers, int n_layers,
-                          unsigned long long* lists, long long list_stride, int* counts, void* stream);
+                          unsigned long long* lists, long long list_stride, int* counts, int* computed, void* stream);
+/* Start values of the MAC descriptor (classification.py:46-49 `amax` over the map) for a layer that runs over a work list WITH tiles /
+ * rows left out (`cvpce_skip_layer.skip` != 0 on a layer launched with mac != NULL): desc[n][desc_off + c] = max over the part of
+ * crop n's map that the list leaves to the constant crop, from the row / column suffix maxima of the constant crop's own map
+ * (f32 [Hc + 1][C] / [Wc + 1][C], entry r = max over rows >= r, last entry 0), indexed by `computed` of that layer. */
+int cvpce_mac_init(float* desc, int n_images, int desc_stride, int desc_off, int C, const float* row_suffix_max,
+                   const float* col_suffix_max, int Hc, int Wc, const int* computed, void* stream);
 /* cvpce_vgg_stem_fused over a work list (tile = 8x8 output pixels).  `in` holds images 0 .. N-2, `const_in` (one image in the
  * same layout) is read as image N - 1. */
 int cvpce_vgg_stem_fused_list(const void* in_nhwc, int in_cstride, const void* const_in, const void* w1, const float* b1,
@@ -204,7 +212,8 @@ int cvpce_vgg_stem_fused_list(const void* in_nhwc, int in_cstride, const void* c
                               const unsigned long long* list, const int* count_dev, void* stream);
 /* cvpce_conv3x3_halo / cvpce_conv3x3_halo_mac (mac != NULL: relu, MAC descriptor in the epilogue; out may then be NULL) over a
  * work list; input pixels in the constant region of their crop are read from image N - 1.  Cout <= 128 runs the wide-tile
- * kernel, mac needs Cout > 128. */
+ * kernel, mac needs Cout > 128.  With mac the maximum is taken over the listed tiles' computed rows only: a list that leaves
+ * tiles / rows out needs `mac` started by cvpce_mac_init (a list of every tile: zeros, as for cvpce_conv3x3_halo_mac). */
 int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
                             int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
                             int fuse_pool2, const unsigned long long* list, const int* count_dev, void* stream);
