@@ -55,6 +55,7 @@ SIGNATURES = {
     'cvpce_mac_init': (c_int, [_fp, c_int, c_int, c_int, c_int, _fp, _fp, c_int, c_int, _ip, _vp]),
     'cvpce_vgg_stem_fused_list': (c_int, [_vp, c_int, _vp, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp, _ip, _vp]),
     'cvpce_conv3x3_halo_list': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 9 + [_vp, _ip, _vp]),
+    'cvpce_conv3x3_halo_strips': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 9 + [_vp, _ip, _vp]),
     'cvpce_detect_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cvpce_detect_postprocess': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), POINTER(c_int),
                                          POINTER(c_int), POINTER(c_int), _fp, _ip, _fp,

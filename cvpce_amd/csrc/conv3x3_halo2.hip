@@ -88,9 +88,15 @@ extern "C" int cvpce_debug_halo2_clock(unsigned long long* host_out) {
 }
 #endif
 
-template <typename E, bool POOL, bool GMAX, bool LIST>
+// STRIP (work-list launches only): a "tile" is THREE strips -- the first 4 output rows of three listed tiles whose other rows are
+// constant (`rows` == 4: a crop's content ends just below a tile boundary).  Run one by one such tiles issue a third of a full
+// tile's MFMAs against a full tile's weight stream, which is what bounds them (profiles/r04_rejected_experiments.md); here patch
+// rows 6s .. 6s + 5 of the 18-row patch belong to strip s, accumulator rows 4s .. 4s + 3 are its outputs, and the three share
+// every weight fragment: 72 MFMAs per step and wave for three tiles' worth of useful rows.
+template <typename E, bool POOL, bool GMAX, bool LIST, bool STRIP = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
-    constexpr int TC = 256, NB = 16;
+    static_assert(!STRIP || LIST, "strips come from a work list");
+    constexpr int TC = 256, NB = 16, NS = STRIP ? 3 : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ap = smem;                 // [3][328][64] bf16
@@ -109,13 +115,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // crop-major with a fixed number of tiles per crop, so a stride that is a multiple of it would hand one workgroup nothing but
     // bottom-row (cut) tiles and another nothing but full ones.  The cout tile stays fixed per workgroup (lbid % ctiles: one
     // weight set per workgroup, and with an even grid per XCD), its group's workgroups split the list entries among them.
-    int my_tiles, l_first = 0;
+    int my_tiles, l_first = 0, l_entries = 0;
     if constexpr (LIST) {
-        const int entries = __builtin_amdgcn_readfirstlane(*a.list_count);      // <= a.ptiles (checked by the list builder)
+        l_entries = __builtin_amdgcn_readfirstlane(*a.list_count);             // <= a.ptiles (checked by the list builder)
+        const int units = STRIP ? (l_entries + 2) / 3 : l_entries;             // STRIP: three list entries make one tile
         const int groups = (int)gridDim.x / a.ctiles;                          // workgroups per cout tile (the host launches grid % ctiles == 0)
-        const int per = (entries + groups - 1) / groups;
+        const int per = (units + groups - 1) / groups;
         l_first = (lbid / a.ctiles) * per;
-        my_tiles = entries - l_first < per ? entries - l_first : per;
+        my_tiles = units - l_first < per ? units - l_first : per;
     } else {
         my_tiles = (a.ntiles - lbid + (int)gridDim.x - 1) / (int)gridDim.x;
     }
@@ -123,8 +130,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     const int total_chunks = my_tiles * nchunks;          // < 2^30: checked on the host
     unsigned long long* llist = reinterpret_cast<unsigned long long*>(smem + G2_LLIST_OFF);
     if constexpr (LIST) {
-        const int staged = my_tiles < G2_MAX_SEQ ? my_tiles : G2_MAX_SEQ;
-        for (int idx = tid; idx < staged; idx += 512) llist[idx] = a.list[l_first + idx];
+        const int staged = my_tiles * NS < G2_MAX_SEQ ? my_tiles * NS : G2_MAX_SEQ;
+        for (int idx = tid; idx < staged; idx += 512) {
+            const int k = l_first * NS + idx;                                    // (STRIP: past the end of the list the last entry is repeated --
+            llist[idx] = a.list[k < l_entries ? k : l_entries - 1];              //  a strip computed twice stores the same values twice)
+        }
         __syncthreads();
     }
 
@@ -162,39 +172,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
 
     // tile seq -> (image, tile row, tile column, cout tile); cout tile fastest.  ext (LIST): the crop's extents on the INPUT tensor
-    auto tile_of = [&](int seq, int& n, int& ty, int& tx, int& ct, int& ext) {
+    auto tile_of = [&](int seq, int* n, int* ty, int* tx, int& ct, int* ext) {
         if constexpr (LIST) {
             ct = lbid % a.ctiles;
-            const unsigned long long e = seq < G2_MAX_SEQ ? llist[seq] : a.list[l_first + seq];
-            const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
-            ext = __builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
-            n = lo >> 16;
-            ty = (lo >> 8) & 0xFF;
-            tx = lo & 0xFF;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k = seq * NS + s, g = l_first * NS + k;
+                const unsigned long long e = k < G2_MAX_SEQ ? llist[k] : a.list[g < l_entries ? g : l_entries - 1];
+                const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+                ext[s] = __builtin_amdgcn_readfirstlane((int)(unsigned)(e >> 32));
+                n[s] = lo >> 16;
+                ty[s] = (lo >> 8) & 0xFF;
+                tx[s] = lo & 0xFF;
+            }
             return;
         }
-        ext = 0;
+        ext[0] = 0;
         const int t = lbid + seq * (int)gridDim.x;
         ct = t % a.ctiles;
         const int p = t / a.ctiles;
-        n = p / a.tiles_per_image;
-        const int r = p - n * a.tiles_per_image;
+        n[0] = p / a.tiles_per_image;
+        const int r = p - n[0] * a.tiles_per_image;
         if (a.mask) {
             const int packed = __builtin_amdgcn_readfirstlane((int)ltile[seq]);
-            ty = packed >> 16;
-            tx = packed & 0xFFFF;
+            ty[0] = packed >> 16;
+            tx[0] = packed & 0xFFFF;
         } else {
-            ty = r / a.tiles_x;
-            tx = r - ty * a.tiles_x;
+            ty[0] = r / a.tiles_x;
+            tx[0] = r - ty[0] * a.tiles_x;
         }
     };
 
     // ---- patch DMA: piece j fills patch rows 8j .. 8j+7 (row = lane>>3, phys chunk = lane&7); pieces dealt
     //      round-robin to the 8 waves (wave w: pieces w, w+8, ...; 6 for w = 0, else 5) ----
     const int npp = (wc == 0) ? 6 : 5;
-    auto issue_patch = [&](int n, int ty, int tx, int c, int buf, int ext) {
-        const int y0 = ty * G2_T - 1, x0 = tx * G2_T - 1;
-        const int ey = (ext >> 12) & 0xFFF, ex = ext & 0xFFF;
+    auto issue_patch = [&](const int* n, const int* ty, const int* tx, int c, int buf, const int* ext) {
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the volatile
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
@@ -206,10 +218,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 const int pp = j * 8 + (ln >> 3);
                 const int py = pp / G2_P, px = pp - py * G2_P;
                 const int lchunk = (ln & 7) ^ g2_swz(py, px);
-                const int y = y0 + py, x = x0 + px;
+                // the tile this patch pixel belongs to: the one tile, or (STRIP) strip py / 6, whose patch rows are 6 s .. 6 s + 5
+                int sn = n[0], sty = ty[0], stx = tx[0], sext = ext[0], ry = py;
+                if constexpr (STRIP) {
+                    const int st = py >= 12 ? 2 : (py >= 6 ? 1 : 0);
+                    ry = py - 6 * st;
+                    sn = st == 0 ? n[0] : (st == 1 ? n[1] : n[2]);
+                    sty = st == 0 ? ty[0] : (st == 1 ? ty[1] : ty[2]);
+                    stx = st == 0 ? tx[0] : (st == 1 ? tx[1] : tx[2]);
+                    sext = st == 0 ? ext[0] : (st == 1 ? ext[1] : ext[2]);
+                }
+                const int ey = (sext >> 12) & 0xFFF, ex = sext & 0xFFF;
+                const int y = sty * G2_T - 1 + ry, x = stx * G2_T - 1 + px;
                 const bool ok = pp < G2_NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                int nn = n;
-                if constexpr (LIST) nn = (y >= ey || x >= ex) ? a.N - 1 : n;    // constant region of the crop: the constant crop's pixel
+                int nn = sn;
+                if constexpr (LIST) nn = (y >= ey || x >= ex) ? a.N - 1 : sn;   // constant region of the crop: the constant crop's pixel
                 const unsigned off = (unsigned)((((size_t)(nn * a.H + y) * a.W + x) * a.Cin + c * 64) * 2) + (unsigned)(lchunk * 16);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p, (lds_void*)(Ap + buf * G2_A_BYTES + j * 1024), 16,
                                                          (int)(ok ? off : 0xFFFFFFF0u), 0, 0, 0);
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         }
     };
     // patch issue pointer: the next flat chunk to fetch and its tile
-    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext;
+    int pi = 0, pi_seq = 0, pi_c = 0, pi_buf = 0, pi_n[NS], pi_ty[NS], pi_tx[NS], pi_ct, pi_ext[NS];
     tile_of(0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext);
     auto issue_next_patch = [&]() {
         if (pi < total_chunks) {
@@ -306,17 +329,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         else                                                                                                   \
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[((P) + 2 * (T)) & 3]) : "v"(e1), "n"(((P) * G2_P + ((T) >> 1)) * 128)); \
     }
+    // patch row P through tap KH feeds output row P - KH -- or (STRIP) row (P % 6) - KH < 4 of strip P / 6 = accumulator row 4 (P / 6) + ...
+#define G2_ROW_KH(T, P, KH)                                                                                    \
+    {                                                                                                          \
+        constexpr int j_ = STRIP ? (P) % 6 - (KH) : (P) - (KH);                                                \
+        constexpr int r_ = STRIP ? 4 * ((P) / 6) + j_ : j_;                                                    \
+        if constexpr (j_ >= 0 && j_ < (STRIP ? 4 : NB)) {                                                      \
+            _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                                \
+                acc[mt_][r_] = E::mfma16(af[(T) % NA][KH][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][r_]);       \
+        }                                                                                                      \
+    }
     // the MFMAs of patch row P: output rows P (kh = 0), P-1 (kh = 1), P-2 (kh = 2) where they exist.  Waits until the
     // row has landed (the two rows prefetched after it may stay in flight); the "+v" tie keeps the compiler from
     // hoisting an MFMA above the wait.
 #define G2_ROW(T, P)                                                                                           \
     {                                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[((P) + 2 * (T)) & 3]));                                 \
-        _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
-            if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
-                _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                            \
-                    acc[mt_][(P) - kh_] = E::mfma16(af[(T) % NA][kh_][mt_], bfr[((P) + 2 * (T)) & 3], acc[mt_][(P) - kh_]); \
-            }                                                                                                  \
+        G2_ROW_KH(T, P, 0) G2_ROW_KH(T, P, 1) G2_ROW_KH(T, P, 2)                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
     // rows 0..15 of step T: prefetch row P + 2, compute row P
@@ -340,9 +369,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // sums nobody stores.  BEFORE / AFTER: what precedes the step's hand-over to the next one (the chunk hand-off in the last step).
 #define G2_ROWS_AND_TAIL(T, TN, BUFB_NEXT, BEFORE)                                                             \
     G2_RP(T, 0) G2_RP(T, 1) G2_RP(T, 2) G2_RP(T, 3) G2_RP(T, 4) G2_RP(T, 5)                                    \
-    if (!LIST || rows_ > 4) { G2_RP(T, 6) G2_RP(T, 7) G2_RP(T, 8) G2_RP(T, 9) }                                \
-    if (!LIST || rows_ > 8) { G2_RP(T, 10) G2_RP(T, 11) G2_RP(T, 12) G2_RP(T, 13) }                            \
-    if (!LIST || rows_ > 12) {                                                                                 \
+    if (!LIST || STRIP || rows_ > 4) { G2_RP(T, 6) G2_RP(T, 7) G2_RP(T, 8) G2_RP(T, 9) }                       \
+    if (!LIST || STRIP || rows_ > 8) { G2_RP(T, 10) G2_RP(T, 11) G2_RP(T, 12) G2_RP(T, 13) }                   \
+    if (!LIST || STRIP || rows_ > 12) {                                                                        \
         G2_RP(T, 14) G2_RP(T, 15)                                                                              \
         BEFORE                                                                                                 \
         G2_SET_E(TN, BUFB_NEXT)                                                                                \
@@ -363,9 +392,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
 
     // ---- prologue ----
-    int seq = 0, cchunk = 0, t_n, t_ty, t_tx, t_ct, t_ext_;
+    int seq = 0, cchunk = 0, t_n[NS], t_ty[NS], t_tx[NS], t_ct, t_ext_[NS];
     tile_of(0, t_n, t_ty, t_tx, t_ct, t_ext_);
-    int rows_ = LIST ? ((t_ext_ >> 24) & 0xFF) : NB;     // output rows of the current tile that are computed (LIST: 4 | 8 | 12 | 16)
+    int rows_ = (LIST && !STRIP) ? ((t_ext_[0] >> 24) & 0xFF) : NB;     // output rows of the current tile that are computed (LIST: 4 | 8 | 12 | 16)
     int n_ct = t_ct;                                    // cout tile of the NEXT chunk's tile
     auto next_ct = [&]() {
         if (cchunk + 1 < nchunks) return t_ct;
@@ -420,8 +449,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 
         if (cchunk + 1 == nchunks) {
             // ---- epilogue of this tile (the next tile's patch, weights and first rows are already in flight) ----
-            const int n = t_n, ty = t_ty, tx = t_tx, ct = t_ct;
-            const int rows_t = rows_;            // (LIST) rows of this tile that were computed: the others are not stored
+            const int ct = t_ct;
+            const int rows_t = STRIP ? 4 : rows_;   // (LIST) rows of this tile (STRIP: of each strip) that were computed: the others are not stored
+            // accumulator row nt belongs to output row nt of the tile -- or (STRIP) to output row nt % 4 of strip nt / 4
+            auto e_n = [&](int nt) { return STRIP ? t_n[(nt >> 2) < NS ? (nt >> 2) : 0] : t_n[0]; };
+            auto e_ty = [&](int nt) { return STRIP ? t_ty[(nt >> 2) < NS ? (nt >> 2) : 0] : t_ty[0]; };
+            auto e_tx = [&](int nt) { return STRIP ? t_tx[(nt >> 2) < NS ? (nt >> 2) : 0] : t_tx[0]; };
+            auto e_row = [&](int nt) { return STRIP ? (nt & 3) : nt; };
+            auto e_live = [&](int nt) { return STRIP ? nt < 12 : (!LIST || nt < rows_t); };
             f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
             load_bias(n_ct, nbias);
             const int col = g2_col(lp);
@@ -432,34 +467,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 // row by rotates -- then one atomic max per (tile, cout) into the zero-initialised descriptor.  Values are
                 // >= 0 after ReLU, so they order like their bit patterns; rounding to bf16 is monotonic, so the maximum
                 // of the fp32 values rounded once equals the maximum of the stored bf16 map, bit for bit.
-                unsigned m[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) m[j] = 0u;
-                if (tx * G2_T + col < a.W) {
+                for (int sg = 0; sg < NS; ++sg) {                    // (STRIP: one maximum per strip = per crop)
+                    unsigned m[8];
 #pragma unroll
-                    for (int nt = 0; nt < NB; ++nt)
-                        if (ty * G2_T + nt < a.H && (!LIST || nt < rows_t)) {      // (LIST: the rows this tile computed; the rest is cvpce_mac_init's)
+                    for (int j = 0; j < 8; ++j) m[j] = 0u;
+                    const int n = t_n[sg], ty = t_ty[sg], tx = t_tx[sg];
+                    if (tx * G2_T + col < a.W) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                m[j] = max(m[j], __float_as_uint(relu_bits(acc[0][nt][j])));
-                                m[4 + j] = max(m[4 + j], __float_as_uint(relu_bits(acc[1][nt][j])));
+                        for (int nt = STRIP ? 4 * sg : 0; nt < (STRIP ? 4 * sg + 4 : NB); ++nt)
+                            if (ty * G2_T + e_row(nt) < a.H && e_live(nt)) {  // (LIST: the rows this tile computed; the rest is cvpce_mac_init's)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    m[j] = max(m[j], __float_as_uint(relu_bits(acc[0][nt][j])));
+                                    m[4 + j] = max(m[4 + j], __float_as_uint(relu_bits(acc[1][nt][j])));
+                                }
                             }
-                        }
-                }
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    unsigned v = m[j];
-                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));   // row_ror:8
-                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));   // row_ror:4
-                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false));   // row_ror:2
-                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false));   // row_ror:1
-                    m[j] = v;
-                }
-                if (lp == 0) {
-                    unsigned* g = reinterpret_cast<unsigned*>(a.gmax) + (size_t)n * a.gmax_stride + a.gmax_off + co;
+                    for (int j = 0; j < 8; ++j) {
+                        unsigned v = m[j];
+                        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));   // row_ror:8
+                        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));   // row_ror:4
+                        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false));   // row_ror:2
+                        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false));   // row_ror:1
+                        m[j] = v;
+                    }
+                    if (lp == 0) {
+                        unsigned* g = reinterpret_cast<unsigned*>(a.gmax) + (size_t)n * a.gmax_stride + a.gmax_off + co;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (co + j < a.Cout) atomicMax(g + j, __float_as_uint(E::widen(E::narrow(__uint_as_float(m[j])))));
+                        for (int j = 0; j < 8; ++j)
+                            if (co + j < a.Cout) atomicMax(g + j, __float_as_uint(E::widen(E::narrow(__uint_as_float(m[j])))));
+                    }
                 }
             }
             if (GMAX && a.out == nullptr) {
@@ -468,12 +507,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                 // rows 2i, 2i+1 are accumulator rows of the same lane; columns 2k, 2k+1 are lanes A[k], B[k] with
                 // A = {0-3,12-15}, B = {4-11}: lane A[k] takes its right neighbour by a row rotate (+4 for lanes 0-3,
                 // -4 for lanes 12-15; bank masks 1 and 8)
-                const int ox = tx * (G2_T / 2) + (col >> 1);
-                const bool lane_ok = (lp < 4 || lp >= 12) && ox < (a.W >> 1);
 #pragma unroll
                 for (int i = 0; i < NB / 2; ++i) {
-                    const int oy = ty * (G2_T / 2) + i;
-                    const size_t opix = (size_t)(n * (a.H >> 1) + oy) * (a.W >> 1) + ox;
+                    const int ox = e_tx(2 * i) * (G2_T / 2) + (col >> 1);
+                    const bool lane_ok = (lp < 4 || lp >= 12) && ox < (a.W >> 1);
+                    const int oy = e_ty(2 * i) * (G2_T / 2) + (e_row(2 * i) >> 1);
+                    const size_t opix = (size_t)(e_n(2 * i) * (a.H >> 1) + oy) * (a.W >> 1) + ox;
                     float r[8];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
@@ -491,19 +530,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
                                 r[4 * mt + j] = fmaxf(v, fmaxf(up, dn));
                             }
                         }
-                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && (!LIST || 2 * i < rows_t) && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
+                    if (lane_ok && oy < (a.H >> 1) && co < a.Cout && e_live(2 * i) && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[0], r[1], r[2], r[3]}));
                         const uint2 h2 = __builtin_bit_cast(uint2, E::pack4(f32x4{r[4], r[5], r[6], r[7]}));
                         *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
                     }
                 }
             } else {
-                const int ox = tx * G2_T + col;
 #pragma unroll
                 for (int nt = 0; nt < NB; ++nt) {
-                    const int oy = ty * G2_T + nt;
-                    const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
-                    const bool store_lane = oy < a.H && ox < a.W && (!LIST || nt < rows_t);     // ragged right / bottom tiles; (LIST) computed rows only
+                    const int ox = e_tx(nt) * G2_T + col;
+                    const int oy = e_ty(nt) * G2_T + e_row(nt);
+                    const size_t opix = (size_t)(e_n(nt) * a.H + oy) * a.W + ox;
+                    const bool store_lane = oy < a.H && ox < a.W && e_live(nt);     // ragged right / bottom tiles; (LIST) computed rows only
                     bool keep = true;                // masked-out pixels (gaps of a level atlas) are stored as zeros
                     if (a.mask) keep = ((lrow[seq * 16 + nt] >> col) & 1u) != 0;
                     f32x4 r0 = acc[0][nt], r1 = acc[1][nt];
@@ -525,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
             ++seq;
             if (seq < my_tiles) {
                 tile_of(seq, t_n, t_ty, t_tx, t_ct, t_ext_);
-                if constexpr (LIST) rows_ = (t_ext_ >> 24) & 0xFF;
+                if constexpr (LIST && !STRIP) rows_ = (t_ext_[0] >> 24) & 0xFF;
             }
         } else {
             ++cchunk;
@@ -546,23 +585,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #undef G2_ROWS_0_15
 #undef G2_RP
 #undef G2_ROW
+#undef G2_ROW_KH
 #undef G2_READ
 #undef G2_SET_E
 #undef G2_PREFETCH_A
 #undef G2_LOAD_A
 }
 
-template <typename E, bool POOL, bool GMAX, bool LIST = false>
+template <typename E, bool POOL, bool GMAX, bool LIST = false, bool STRIP = false>
 static int launch_halo2(Halo2Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 255) / 256;
     a.ntiles = a.ptiles * a.ctiles;
     const int smem = a.mask ? G2_SMEM_MASKED : (LIST ? G2_SMEM_LIST : 3 * G2_A_BYTES);
-    if (!cvpce_smem_attr_done<conv3x3_halo2_kernel<E, POOL, GMAX, LIST>>((const void*)conv3x3_halo2_kernel<E, POOL, GMAX, LIST>, G2_SMEM_MASKED))
+    if (!cvpce_smem_attr_done<conv3x3_halo2_kernel<E, POOL, GMAX, LIST, STRIP>>((const void*)conv3x3_halo2_kernel<E, POOL, GMAX, LIST, STRIP>, G2_SMEM_MASKED))
         return CVPCE_ERR_LAUNCH;
     int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
     if (LIST) grid = grid < a.ctiles ? a.ctiles : grid / a.ctiles * a.ctiles;     // (work-list launches: the same number of workgroups per cout tile)
     if (a.mask && (a.ntiles + grid - 1) / grid > G2_MAX_SEQ) return CVPCE_ERR_ARG;   // the workgroup's tile list lives in LDS
-    hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX, LIST>), dim3(grid), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo2_kernel<E, POOL, GMAX, LIST, STRIP>), dim3(grid), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
@@ -659,9 +699,9 @@ int cvpce_conv3x3_halo_wide_list(const void* in, const void* wgt, const float* b
                                  int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, const unsigned long long* list,
                                  const int* count_dev, void* stream);
 
-extern "C" int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
-                                       int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
-                                       int fuse_pool2, const unsigned long long* list, const int* count_dev, void* stream) {
+static int halo_list_launch(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                            int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                            int fuse_pool2, const unsigned long long* list, const int* count_dev, bool strips, void* stream) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || (!out && !mac) || !list || !count_dev) return CVPCE_ERR_ARG;
     if (mac && (!relu || Cout <= 128 || mac_off < 0 || mac_off + Cout > mac_stride)) return CVPCE_ERR_ARG;
@@ -670,7 +710,10 @@ extern "C" int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const fl
     if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
     if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
     if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31) || N > 65535) return CVPCE_ERR_ARG;
-    if (Cout <= 128) return cvpce_conv3x3_halo_wide_list(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, list, count_dev, stream);
+    if (Cout <= 128) {
+        if (strips) return CVPCE_ERR_ARG;               // (the wide-tile kernel has no strip mode)
+        return cvpce_conv3x3_halo_wide_list(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, list, count_dev, stream);
+    }
     Halo2Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)out;
     a.gmax = mac; a.gmax_stride = mac_stride; a.gmax_off = mac_off;
@@ -685,6 +728,22 @@ extern "C" int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const fl
     a.list = list; a.list_count = count_dev;
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (strips) {
+        if (mac) return fuse_pool2 ? launch_halo2<ElemBF16, true, true, true, true>(a, s) : launch_halo2<ElemBF16, false, true, true, true>(a, s);
+        return fuse_pool2 ? launch_halo2<ElemBF16, true, false, true, true>(a, s) : launch_halo2<ElemBF16, false, false, true, true>(a, s);
+    }
     if (mac) return fuse_pool2 ? launch_halo2<ElemBF16, true, true, true>(a, s) : launch_halo2<ElemBF16, false, true, true>(a, s);
     return fuse_pool2 ? launch_halo2<ElemBF16, true, false, true>(a, s) : launch_halo2<ElemBF16, false, false, true>(a, s);
+}
+
+extern "C" int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                                       int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                                       int fuse_pool2, const unsigned long long* list, const int* count_dev, void* stream) {
+    return halo_list_launch(in, wgt, bias, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, list, count_dev, false, stream);
+}
+
+extern "C" int cvpce_conv3x3_halo_strips(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                                         int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                                         int fuse_pool2, const unsigned long long* strip_list, const int* count_dev, void* stream) {
+    return halo_list_launch(in, wgt, bias, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, strip_list, count_dev, true, stream);
 }

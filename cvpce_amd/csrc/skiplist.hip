@@ -17,6 +17,7 @@
 //   entry = ((rows << 24 | ey_in << 12 | ex_in) << 32) | (n << 16) | (ty << 8) | tx
 // rows = how many of the tile's 16 conv-output rows (before a fused pool) are NOT wholly constant, rounded up to 4: the halo
 // kernels stop streaming patch rows behind them (rows of a tile below the crop's content extent are never read by anyone).
+// Layers with skip == 3 get a second list, the STRIP list: their tiles with rows == 4, which conv3x3_halo2.hip computes three at a time.
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 
@@ -27,9 +28,9 @@ struct WorklistArgs {
     int n, S, nl;
     unsigned pool_mask;              // bit i: op i of the pass is a 2x2 pool (else a 3x3 conv)
     cvpce_skip_layer L[SKL_MAX_LAYERS];
-    unsigned long long* lists;       // [nl][stride]
+    unsigned long long* lists;       // [2 * nl][stride]: the layers' lists, then their strip lists
     long long stride;
-    int* counts;                     // [2 * nl]: tiles listed per layer, then sixteenths of a tile's MFMA work actually performed per layer
+    int* counts;                     // [3 * nl]: tiles listed per layer, sixteenths of a tile's MFMA work actually performed per layer, strip-list entries
     int* computed;                   // optional [nl][n][2]: per crop, the conv-output rows a layer computes (rows below are left to the
                                      // constant crop) and its listed tile columns -- what cvpce_mac_init needs
 };
@@ -43,79 +44,90 @@ __device__ __forceinline__ int skl_extent(int e0, int S, unsigned pool_mask, int
 
 __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
     __shared__ int s_cnt[1024];
-    __shared__ int s_base, s_units;
+    __shared__ int s_base, s_sbase, s_units;
     const cvpce_skip_layer L = a.L[blockIdx.x];
     const int tid = threadIdx.x;
     const int tiles_y = (L.H + L.tile_h - 1) / L.tile_h, tiles_x = (L.W + L.tile_w - 1) / L.tile_w;
     unsigned long long* list = a.lists + (long long)blockIdx.x * a.stride;
-    if (tid == 0) s_base = s_units = 0;
+    unsigned long long* slist = a.lists + (long long)(a.nl + blockIdx.x) * a.stride;     // the layer's strip list (skip == 3)
+    if (tid == 0) s_base = s_sbase = s_units = 0;
     __syncthreads();
+    // exclusive scan of one value per thread over the 1024 slots (Hillis-Steele) -> (this thread's offset, the total)
+    auto scan = [&](int v, int& total) {
+        s_cnt[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int t = tid >= d ? s_cnt[tid - d] : 0;
+            __syncthreads();
+            s_cnt[tid] += t;
+            __syncthreads();
+        }
+        const int off = s_cnt[tid] - v;
+        total = s_cnt[1023];
+        __syncthreads();
+        return off;
+    };
     for (int n0 = 0; n0 < a.n; n0 += 1024) {
         const int n = n0 + tid;
-        int ny = 0, nx = 0, eiy = 0, eix = 0, eoy_ = 0;
+        int ny = 0, nx = 0, eiy = 0, eix = 0, last_rows = 16;
         if (n < a.n) {
             const bool is_const = n == a.n - 1;
             const int ey0 = is_const ? a.S : a.ext0[2 * n], ex0 = is_const ? a.S : a.ext0[2 * n + 1];
             ny = tiles_y; nx = tiles_x;
             if (L.skip) {
                 const int eoy = skl_extent(ey0, a.S, a.pool_mask, L.out_ops, L.H), eox = skl_extent(ex0, a.S, a.pool_mask, L.out_ops, L.W);
-                eoy_ = eoy;
                 const int cy = (eoy + L.tile_h - 1) / L.tile_h, cx = (eox + L.tile_w - 1) / L.tile_w;   // tile row ty is computed iff ty * tile_h < eoy
                 ny = cy < tiles_y ? cy : tiles_y;
                 nx = cx < tiles_x ? cx : tiles_x;
+                if (L.skip >= 2 && ny > 0) {
+                    // the last listed tile row: its conv-output rows that are not constant, in sixteenths of the tile, rounded up to 4
+                    const int left = eoy - (ny - 1) * L.tile_h;
+                    const int act = left < L.tile_h ? left : L.tile_h;
+                    last_rows = ((act * 16 + L.tile_h - 1) / L.tile_h + 3) & ~3;
+                    if (last_rows > 16) last_rows = 16;
+                }
             }
             eiy = skl_extent(ey0, a.S, a.pool_mask, L.in_ops, L.in_H);
             eix = skl_extent(ex0, a.S, a.pool_mask, L.in_ops, L.in_W);
         }
-        // exclusive scan of the per-crop tile counts (Hillis-Steele over the 1024 slots)
-        const int cnt = ny * nx;
-        s_cnt[tid] = cnt;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int v = tid >= d ? s_cnt[tid - d] : 0;
-            __syncthreads();
-            s_cnt[tid] += v;
-            __syncthreads();
-        }
+        // a last tile row with 4 useful rows goes to the strip list (three such tiles are computed as one, conv3x3_halo2.hip STRIP)
+        const bool strips = L.skip >= 3 && ny > 0 && last_rows == 4;
+        const int scnt = strips ? nx : 0, cnt = ny * nx - scnt;
         if (a.computed && n < a.n && blockIdx.y == 0) {
             // rows [0, rc) of the conv output (before a fused pool) are computed for this crop: whole tile rows, the last one cut
-            int rc = ny * 16;
-            if (L.skip >= 2 && ny > 0) {
-                const int left = eoy_ - (ny - 1) * L.tile_h;
-                const int act = left < L.tile_h ? left : L.tile_h;
-                int rows = ((act * 16 + L.tile_h - 1) / L.tile_h + 3) & ~3;
-                rc = (ny - 1) * 16 + (rows > 16 ? 16 : rows);
-            }
-            a.computed[((long long)blockIdx.x * a.n + n) * 2] = rc;
+            a.computed[((long long)blockIdx.x * a.n + n) * 2] = ny > 0 ? (ny - 1) * 16 + last_rows : 0;
             a.computed[((long long)blockIdx.x * a.n + n) * 2 + 1] = nx;
         }
-        const int base = s_base + s_cnt[tid] - cnt;
-        const int chunk_total = s_cnt[1023];
-        __syncthreads();
-        if (tid == 0) s_base += chunk_total;
-        // entries of this thread's crop; blockIdx.y splits the crops among workgroups (every workgroup runs the same scan)
+        int total, stotal;
+        const int base0 = s_base, sbase0 = s_sbase;          // (read before the scans' barriers; updated behind them)
+        const int base = base0 + scan(cnt, total);
+        const int sbase = sbase0 + scan(scnt, stotal);
+        if (tid == 0) { s_base = base0 + total; s_sbase = sbase0 + stotal; }
+        // entries of this thread's crop; blockIdx.y splits the crops among workgroups (every workgroup runs the same scans)
         if (n < a.n && (n % (int)gridDim.y) == (int)blockIdx.y) {
             const unsigned ext = ((unsigned)eiy << 12) | (unsigned)eix;
             int units = 0;
-            for (int j = 0; j < cnt; ++j) {
+            for (int j = 0; j < cnt + scnt; ++j) {
                 const int ty = j / nx, tx = j - ty * nx;
-                // active conv-output rows of this tile, in sixteenths of the tile height, rounded up to a multiple of 4
-                int rows = 16;
-                if (L.skip >= 2) {
-                    const int left = eoy_ - ty * L.tile_h;
-                    const int act = left < L.tile_h ? left : L.tile_h;
-                    rows = ((act * 16 + L.tile_h - 1) / L.tile_h + 3) & ~3;
-                    if (rows > 16) rows = 16;
+                const int rows = (ty == ny - 1) ? last_rows : 16;
+                const unsigned long long e = ((unsigned long long)(((unsigned)rows << 24) | ext) << 32) |
+                                             (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
+                if (j < cnt) {
+                    list[base + j] = e;
+                    units += rows < 16 ? rows + 1 : 16;      // a tile cut at `rows` streams patch rows 0 .. rows + 1: (rows + 1) / 16 of its MFMAs
+                } else {
+                    slist[sbase + j - cnt] = e;
+                    units += 4;                              // three strips share one pass of 72 MFMAs per step (a full tile: 96)
                 }
-                list[base + j] = ((unsigned long long)(((unsigned)rows << 24) | ext) << 32) |
-                                 (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
-                units += rows < 16 ? rows + 1 : 16;          // a tile cut at `rows` streams patch rows 0 .. rows + 1: (rows + 1) / 16 of its MFMAs
             }
             atomicAdd(&s_units, units);
         }
         __syncthreads();
     }
-    if (tid == 0 && blockIdx.y == 0) a.counts[blockIdx.x] = s_base;
+    if (tid == 0 && blockIdx.y == 0) {
+        a.counts[blockIdx.x] = s_base;
+        a.counts[2 * a.nl + blockIdx.x] = s_sbase;
+    }
     if (tid == 0) atomicAdd(&a.counts[a.nl + blockIdx.x], s_units);       // (summed over the workgroups that split the crops; zeroed by the host wrapper)
 }
 

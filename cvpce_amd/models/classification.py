@@ -46,6 +46,10 @@ SKIP_ROWS = _os.environ.get('CVPCE_SKIP_ROWS', '1') != '0'
 # leave out is the constant crop's own map there, whose row / column suffix maxima are tabulated once per engine and start the
 # descriptor (`cvpce_mac_init`) before the kernels take their atomic maxima over what they do compute.  A/B switch.
 SKIP_MAC = _os.environ.get('CVPCE_SKIP_MAC', '1') != '0'
+# ... and tiles of which only the first 4 rows are not constant (a crop's content ending just below a tile boundary: conv4_2 / conv4_3
+# on the bench's boxes) are computed three at a time (`cvpce_conv3x3_halo_strips`): alone such a tile issues a third of the MFMAs of a
+# full one against the same weight stream, which bounds it.  A/B switch.
+SKIP_STRIPS = _os.environ.get('CVPCE_SKIP_STRIPS', '1') != '0'
 
 
 def _passes(n, step, longest):
@@ -125,7 +129,7 @@ class MACVGGEngine:
         per step, pool_mask), or None when this engine's plan is not stem + 3x3 halo convolutions with the MAC descriptors fused
         (then nothing is skipped).  Extent bookkeeping (include/cvpce_amd.h `cvpce_skip_layer`): the pass is a chain of ops on
         the crop -- conv (+1) and pool (halve upwards) -- and every tensor is named by the number of ops before it."""
-        key = (size, SKIP_ROWS, SKIP_MAC)
+        key = (size, SKIP_ROWS, SKIP_MAC, SKIP_STRIPS)
         if key in self._skip_plans:
             return self._skip_plans[key]
         steps, layers, chain = None, [], []
@@ -154,7 +158,8 @@ class MACVGGEngine:
                     th, tw, oh = th // 2, tw // 2, h // 2
                 if not store:
                     oh, th, tw = h, 16, 16
-                layers.append(ops.skip_layer(oh, oh, th, tw, len(chain), h, h, in_ops, 0 if (mac and not SKIP_MAC) else (2 if SKIP_ROWS else 1)))
+                mode = 0 if (mac and not SKIP_MAC) else (1 if not SKIP_ROWS else (3 if (SKIP_STRIPS and pc.cout > 128) else 2))
+                layers.append(ops.skip_layer(oh, oh, th, tw, len(chain), h, h, in_ops, mode))
                 steps.append(('conv', pc, pool, mac, store))
                 i += (3 if pool else 2) if mac else 1
                 if not mac and i < len(plan) and plan[i][0] != 'conv' and plan[i][0] != 'conv_pool':
@@ -226,8 +231,10 @@ class MACVGGEngine:
         off = 0
         t = ops.vgg_stem_list(xb, const_in, self.stem, lists[0], counts[0:1])
         for li, (kind, pc, pool, mac, store) in enumerate(steps[1:], start=1):
+            nl = len(steps)
             t = ops.conv2d_list(t, pc, lists[li], counts[li:li + 1], act=1, pool=pool, mac=desc if mac else None, mac_off=off, store=store,
-                                units=counts[len(steps) + li:len(steps) + li + 1])
+                                units=counts[nl + li:nl + li + 1],
+                                strips=(lists[nl + li], counts[2 * nl + li:2 * nl + li + 1]) if layers[li][-1] == 3 else None)
             if mac:
                 off += pc.cout
         return desc[:n]

@@ -403,13 +403,13 @@ def skip_layer(h, w, tile_h, tile_w, out_ops, in_h, in_w, in_ops, skip):
 
 def embed_worklists(ext0, n_images, size, pool_mask, layers, max_tiles, want_computed=False):
     """ext0 (n_images - 1, 2) int32 (the last image is the implied constant crop); pool_mask: the pass's op chain (bit i: op i is
-    a 2x2 pool, else a 3x3 conv); layers: list of `skip_layer` -> (lists (L, n_images * max_tiles) int64, counts (2 L,) int32:
-    tiles per layer, then the layers' MFMA work in sixteenths of a tile [, computed (L, n_images, 2) int32: conv rows computed /
+    a 2x2 pool, else a 3x3 conv); layers: list of `skip_layer` -> (lists (2 L, n_images * max_tiles) int64: the layers' lists, then
+    their strip lists; counts (3 L,) int32: tiles per layer, the layers' MFMA work in sixteenths of a tile, strip entries [, computed (L, n_images, 2) int32: conv rows computed /
     tile columns listed per crop]), all on the device, no synchronisation."""
     _need_cuda(ext0)
     dev = ext0.device if ext0 is not None else torch.device('cuda', torch.cuda.current_device())
-    lists = torch.empty((len(layers), n_images * max_tiles), dtype=torch.int64, device=dev)
-    counts = torch.empty((2 * len(layers),), dtype=torch.int32, device=dev)
+    lists = torch.empty((2 * len(layers), n_images * max_tiles), dtype=torch.int64, device=dev)       # rows L ..: the layers' strip lists
+    counts = torch.empty((3 * len(layers),), dtype=torch.int32, device=dev)
     computed = torch.empty((len(layers), n_images, 2), dtype=torch.int32, device=dev) if want_computed else None
     T.embed_worklists(ext0, int(n_images), int(size), int(pool_mask), [v for l in layers for v in l], lists, counts, computed)
     return (lists, counts, computed) if want_computed else (lists, counts)
@@ -438,9 +438,10 @@ def vgg_stem_list(x, const_in, ps, work, count, units=None):
     return out
 
 
-def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True, units=None):
+def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True, units=None, strips=None):
     """3x3 / s1 / p1 conv (+ReLU, + fused MaxPool2d(2,2), + fused MAC descriptor) over a work list; x (N,H,W,Cin) with the
-    constant crop as image N - 1.  Returns the output tensor (None with store=False)."""
+    constant crop as image N - 1.  strips = (strip list, its count): a second launch computes the layer's strip list (tiles with
+    only 4 useful rows, three at a time) into the same output.  Returns the output tensor (None with store=False)."""
     _need_cuda(x, work, count, mac)
     assert x.dtype == BF16 and pc.dtype == BF16 and x.is_contiguous() and x.dim() == 4
     assert pc.cin_pad % 64 == 0 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and pc.cout % 8 == 0 and pc.cout > 64
@@ -453,6 +454,9 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     T.conv3x3_halo_list(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), work, count)
+    if strips is not None:
+        assert pc.cout > 128
+        T.conv3x3_halo_strips(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
     if prof is not None:
         e1.record()
         wide = pc.cout <= 128

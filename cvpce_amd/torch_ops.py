@@ -203,11 +203,11 @@ def _mac_init(desc, off, row_suffix_max, col_suffix_max, computed):
 @_op('embed_worklists(Tensor? ext0, int n_images, int size, int pool_mask, int[] layers, Tensor(a!) lists, Tensor(b!) counts, '
      'Tensor(c!)? computed) -> ()')
 def _embed_worklists(ext0, n_images, size, pool_mask, layers, lists, counts, computed):
-    """layers: 9 ints per layer in the field order of `cvpce_skip_layer`; lists (n_layers, stride) int64; counts (2 * n_layers,) int32 (tiles, then row units)."""
+    """layers: 9 ints per layer in the field order of `cvpce_skip_layer`; lists (2 * n_layers, stride) int64 (lists, then strip lists); counts (3 * n_layers,) int32 (tiles, row units, strip entries)."""
     nf = len(_lib.SkipLayer._fields_)
     nl = len(layers) // nf
-    if len(layers) != nl * nf or lists.dtype != torch.int64 or not lists.is_contiguous() or lists.shape[0] != nl or counts.dtype != torch.int32 \
-            or counts.numel() != 2 * nl or (ext0 is not None and (ext0.dtype != torch.int32 or not ext0.is_contiguous() or ext0.numel() < 2 * (n_images - 1))):
+    if len(layers) != nl * nf or lists.dtype != torch.int64 or not lists.is_contiguous() or lists.shape[0] != 2 * nl or counts.dtype != torch.int32 \
+            or counts.numel() != 3 * nl or (ext0 is not None and (ext0.dtype != torch.int32 or not ext0.is_contiguous() or ext0.numel() < 2 * (n_images - 1))):
         raise RuntimeError('embed_worklists: bad argument shapes / types')
     arr = (_lib.SkipLayer * nl)(*[_lib.SkipLayer(*[int(v) for v in layers[i * nf:(i + 1) * nf]]) for i in range(nl)])
     if computed is not None and (computed.dtype != torch.int32 or not computed.is_contiguous() or computed.numel() < 2 * nl * n_images):
@@ -227,14 +227,24 @@ def _vgg_stem_fused_list(x, const_in, w1, b1, w2, b2, out, work, count):
                                         _stream()), 'cvpce_vgg_stem_fused_list')
 
 
+def _halo_list(fn, what, x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, relu, pool, work, count):
+    n, h, w, cin = x.shape
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or work.dtype != torch.int64 or count.dtype != torch.int32:
+        raise RuntimeError(f'{what}: bf16 activations, int64 work list, int32 count')
+    check(fn(_p(x), _p(weight), _p(bias), _p(out), _p(mac), mac.shape[1] if mac is not None else 0, mac_off, n, h, w,
+             cin, cout, k_pad, cout_pad, relu, pool, _p(work), _p(count), _stream()), what)
+
+
 @_op('conv3x3_halo_list(Tensor x, Tensor weight, Tensor? bias, Tensor(a!)? out, Tensor(b!)? mac, int mac_off, int cout, int k_pad, '
      'int cout_pad, int relu, int pool, Tensor work, Tensor count) -> ()')
 def _conv3x3_halo_list(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, relu, pool, work, count):
-    n, h, w, cin = x.shape
-    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or work.dtype != torch.int64 or count.dtype != torch.int32:
-        raise RuntimeError('cvpce_conv3x3_halo_list: bf16 activations, int64 work list, int32 count')
-    check(lib.cvpce_conv3x3_halo_list(_p(x), _p(weight), _p(bias), _p(out), _p(mac), mac.shape[1] if mac is not None else 0, mac_off, n, h, w,
-                                      cin, cout, k_pad, cout_pad, relu, pool, _p(work), _p(count), _stream()), 'cvpce_conv3x3_halo_list')
+    _halo_list(lib.cvpce_conv3x3_halo_list, 'cvpce_conv3x3_halo_list', x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, relu, pool, work, count)
+
+
+@_op('conv3x3_halo_strips(Tensor x, Tensor weight, Tensor? bias, Tensor(a!)? out, Tensor(b!)? mac, int mac_off, int cout, int k_pad, '
+     'int cout_pad, int relu, int pool, Tensor work, Tensor count) -> ()')
+def _conv3x3_halo_strips(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, relu, pool, work, count):
+    _halo_list(lib.cvpce_conv3x3_halo_strips, 'cvpce_conv3x3_halo_strips', x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, relu, pool, work, count)
 
 
 @_op('pack_embed_input(Tensor images, Tensor(a!) out, int to_tanh, float[] mean, float[] std) -> ()')

@@ -184,8 +184,8 @@ typedef struct {
     int out_ops;               /* ops of the pass up to and including this layer (= the name of its output tensor) */
     int in_H, in_W;            /* the layer's INPUT tensor */
     int in_ops;                /* ... and its name */
-    int skip;                  /* 0: list every tile (layers whose epilogue needs every tile: the fused MAC maximum); 1: leave out the tiles
-                                  that are wholly constant; 2: ... and cut the listed tiles at their last non-constant row (`rows`) */
+    int skip;                  /* 0: list every tile; 1: leave out the tiles that are wholly constant; 2: ... and cut the listed tiles at their
+                                  last non-constant row (`rows`); 3: ... and move the tiles with rows == 4 to the layer's STRIP list */
 } cvpce_skip_layer;
 /* ext0 [n_images - 1][2] (cvpce_crop_extents; the constant crop, image n_images - 1, is implied), layers [host] ->
  * lists[l * list_stride + i] for i < counts[l] (device): the tiles layer l computes, crop-major,
@@ -193,8 +193,11 @@ typedef struct {
  * (ey_in / ex_in < 4096: the INPUT tensor's extents of crop n; rows in {4, 8, 12, 16}: the tile's conv-output rows that are not
  * wholly constant, rounded up to 4 -- the halo kernels compute only those, the rest of the tile is neither computed nor stored)
  * list_stride >= n_images * tiles of the largest layer.  No host synchronisation: the kernels read counts[l] themselves.
- * counts has 2 * n_layers entries: counts[n_layers + l] = the MFMA work layer l performs, in sixteenths of a full tile (a tile cut
- * at `rows` < 16 streams rows + 1 of its 16 row groups) -- what `roofline` counts as executed FLOPs.
+ * `lists` has 2 * n_layers rows: row n_layers + l is layer l's STRIP list (skip == 3: its tiles with rows == 4, same entry format,
+ * for cvpce_conv3x3_halo_strips; empty otherwise).
+ * counts has 3 * n_layers entries: counts[n_layers + l] = the MFMA work layer l performs, in sixteenths of a full tile (a tile cut
+ * at `rows` < 16 streams rows + 1 of its 16 row groups, a strip counts 4) -- what `roofline` counts as executed FLOPs;
+ * counts[2 * n_layers + l] = entries of layer l's strip list.
  * computed (optional, [n_layers][n_images][2]): per layer and crop, (conv-output rows computed, tile columns listed) -- the region
  * cvpce_mac_init has to cover from the constant crop. */
 int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsigned pool_mask, const cvpce_skip_layer* layers, int n_layers,
@@ -241,6 +244,14 @@ size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k);
 int cvpce_match_topk(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
                      int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
                      long long* out_idx, float* out_dist, void* stream);
+
+/* cvpce_conv3x3_halo_list's companion for a layer's STRIP list (Cout > 128 only): three listed tiles of which only the first 4
+ * output rows are not constant are computed as ONE tile -- patch rows 6 s .. 6 s + 5 and accumulator rows 4 s .. 4 s + 3 belong to
+ * strip s, all three share every weight fragment.  Same operands as cvpce_conv3x3_halo_list; writes the strips' rows into the same
+ * `out` (and `mac`) the list launch of the layer writes the other tiles into. */
+int cvpce_conv3x3_halo_strips(const void* in, const void* wgt, const float* bias, void* out, float* mac, int mac_stride,
+                              int mac_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
+                              int fuse_pool2, const unsigned long long* strip_list, const int* count_dev, void* stream);
 
 /* ---- fp16 twins: the detector's opt-in accuracy mode ------------------------------------------------------------------
  * `gln(..., precision='fp16')` / `GaussianLayerNetwork.set_precision('fp16')` stores the detector's weights and inter-layer

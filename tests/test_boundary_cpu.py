@@ -50,7 +50,7 @@ def test_torch_ops_registered_for_the_gpu_only():
         assert base in declared or base + '_bf16' in declared, t
     declared -= twins
     # (the two 3x3 halo entry points share one op: Cout <= 128 is forwarded to the wide-tile kernel inside the library)
-    assert len(torch_ops.NAMES) == len(declared) == 29   # (two halo entry points share an op; atlas_copy has two; round 4: the six work-list / extent / MAC-start entry points)
+    assert len(torch_ops.NAMES) == len(declared) == 30   # (two halo entry points share an op; atlas_copy has two; round 4: the seven work-list / extent / MAC-start entry points)
     for name in torch_ops.NAMES:
         op = getattr(torch.ops.cvpce_amd, name)
         assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'cvpce_amd::{name}', 'CPU')

@@ -115,8 +115,9 @@ def test_worklists_match_python_model(cuda, skip_rows):
     from cvpce_amd import ops, synthetic
     enc = synthetic.synthetic_macvgg(seed=1).cuda()
     steps, layers, pool_mask = enc.engine().skip_plan(S)
-    m = 2 if skip_rows else 1
-    assert len(layers) == 12 and [l[-1] for l in layers] == [1] + [m] * 11     # (conv4_3 / conv5_3, the MAC layers, skip too: cvpce_mac_init covers what they leave out)
+    # stem: whole tiles; conv2_x (wide-tile kernel): rows cut; conv3_1 .. conv5_3: rows cut + strip lists (the MAC layers conv4_3 /
+    # conv5_3 skip too: cvpce_mac_init covers what they leave out)
+    assert len(layers) == 12 and [l[-1] for l in layers] == ([1] + [2] * 2 + [3] * 9 if skip_rows else [1] * 12)
     # the op chain of VGG16 cfg 'D' up to relu5_3: 2 convs, pool, 2 convs, pool, 3 convs, pool, 3 convs, pool, 3 convs
     assert [(pool_mask >> i) & 1 for i in range(17)] == [0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]
     assert [l[4] for l in layers] == [3, 4, 6, 7, 8, 10, 11, 12, 14, 15, 16, 17] and [l[7] for l in layers] == [0, 3, 4, 6, 7, 8, 10, 11, 12, 14, 15, 16]
@@ -125,29 +126,40 @@ def test_worklists_match_python_model(cuda, skip_rows):
     ext = torch.stack((torch.randint(1, S + 1, (n,), generator=g), torch.full((n,), S)), dim=1).to(torch.int32)
     ext[::3] = ext[::3].flip(1)                                  # tall boxes: columns
     ext[5] = torch.tensor([S, S]); ext[6] = torch.tensor([0, 0]); ext[7] = torch.tensor([1, S]); ext[8] = torch.tensor([S, 255])
-    lists, counts = ops.embed_worklists(ext.cuda(), n + 1, S, pool_mask, layers, 256)
-    lists, counts = lists.cpu(), counts.cpu().tolist()
+    lists, counts, computed = ops.embed_worklists(ext.cuda(), n + 1, S, pool_mask, layers, 256, want_computed=True)
+    lists, counts, computed = lists.cpu(), counts.cpu().tolist(), computed.cpu()
+    nl = len(layers)
+    assert lists.shape[0] == 2 * nl and len(counts) == 3 * nl
     allext = ext.tolist() + [[S, S]]
     for li, L in enumerate(layers):
         h, w, th, tw, out_ops, ih, iw, in_ops, skip = L
         ty_n, tx_n = -(-h // th), -(-w // tw)
-        want = []
+        want, swant, comp = [], [], []
         for c, (ey0, ex0) in enumerate(allext):
             ny, nx = ty_n, tx_n
             if skip:
                 ny = min(ty_n, -(-_extent(ey0, pool_mask, out_ops, h) // th))
                 nx = min(tx_n, -(-_extent(ex0, pool_mask, out_ops, w) // tw))
             ext_in = (_extent(ey0, pool_mask, in_ops, ih) << 12) | _extent(ex0, pool_mask, in_ops, iw)
+            last = 16
             for ty in range(ny):
                 rows = 16                                        # conv-output rows of the tile that are not constant, rounded up to 4
-                if skip >= 2:
+                if skip >= 2 and ty == ny - 1:
                     act = min(th, _extent(ey0, pool_mask, out_ops, h) - ty * th)
-                    rows = min(16, (-(-act * 16 // th) + 3) // 4 * 4)
-                want += [(((rows << 24) | ext_in) << 32) | (c << 16) | (ty << 8) | tx for tx in range(nx)]
-        assert counts[li] == len(want), (li, counts[li], len(want))
+                    last = rows = min(16, (-(-act * 16 // th) + 3) // 4 * 4)
+                entries = [(((rows << 24) | ext_in) << 32) | (c << 16) | (ty << 8) | tx for tx in range(nx)]
+                if skip >= 3 and rows == 4 and ty == ny - 1:
+                    swant += entries                             # a last tile row with 4 useful rows: the strip list
+                else:
+                    want += entries
+            comp.append([(ny - 1) * 16 + last if ny else 0, nx])
+        assert counts[li] == len(want) and counts[2 * nl + li] == len(swant), (li, counts[li], len(want), counts[2 * nl + li], len(swant))
         rows_of = [(e >> 56) & 0xFF for e in want]
-        assert counts[len(layers) + li] == sum(r + 1 if r < 16 else 16 for r in rows_of), li       # MFMA work in sixteenths of a tile
-        assert lists[li, :len(want)].tolist() == want, li
+        assert counts[nl + li] == sum(r + 1 if r < 16 else 16 for r in rows_of) + 4 * len(swant), li       # MFMA work in sixteenths of a tile
+        assert lists[li, :len(want)].tolist() == want and lists[nl + li, :len(swant)].tolist() == swant, li
+        assert computed[li].tolist() == comp, li
+        n_strips = locals().get('n_strips', 0) + len(swant)
+    assert (n_strips > 0) == bool(skip_rows)                     # the random extents do produce strip-list tiles
 
 
 @pytest.mark.parametrize('batch_norm', [False, True])
