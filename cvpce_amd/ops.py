@@ -118,7 +118,7 @@ class ConvProfile:
             d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'flops_executed': 0.0, 'ms': 0.0})
             d['launches'] += 1
             d['flops'] += flops
-            d['flops_executed'] += float(rec[4].item()) * rec[5] if len(rec) > 4 else flops
+            d['flops_executed'] += (float(rec[4].item()) * rec[5] if rec[4] is not None else 0.0) if len(rec) > 4 else flops
             d['ms'] += e0.elapsed_time(e1)
         return out
 
@@ -454,15 +454,20 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     T.conv3x3_halo_list(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), work, count)
-    if strips is not None:
-        assert pc.cout > 128
-        T.conv3x3_halo_strips(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
     if prof is not None:
         e1.record()
         wide = pc.cout <= 128
         tile_flops = 2.0 * 16 * (32 if wide else 16) * pc.cout * 9 * pc.cin
+        # (`units` counts the layer's whole MFMA work, its strip launch included: the strip record below carries none)
         prof.records.append(('conv3x3_halo3_kernel' if wide else 'conv3x3_halo2_kernel', 2.0 * (n - 1) * h * w * pc.cout * 9 * pc.cin, e0, e1)
                             + ((units, tile_flops / 16) if units is not None else (count, tile_flops)))
+    if strips is not None:
+        assert pc.cout > 128
+        T.conv3x3_halo_strips(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
+        if prof is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record()
+            prof.records.append(('conv3x3_halo2_kernel', 0.0, e1, e2, None, 0.0))
     return out
 
 
