@@ -484,6 +484,9 @@ def run_pipeline(args, rank, local_rank, world, dev):
         workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
                      'match_stress_configs3': match_stress_cases(dev, 200, 3),
                      'embed_planted_boxes': embed_planted_boxes(dev, enc, images[0], ipg * dpi)}
+        fs = fitted_scenes_pipeline(dev, clf, ipg, dpi, args.image_size, max(5, args.steps // 2), args.detector_precision)
+        if fs is not None:
+            workloads['pipeline_fitted_scenes'] = fs
 
     peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
     if roofline is not None and peaks is not None:
@@ -543,6 +546,38 @@ def run_pipeline(args, rank, local_rank, world, dev):
         if val is not None:
             line[key] = val
     return line
+
+
+def fitted_scenes_pipeline(dev, clf, ipg, dpi, image_size, steps, precision):
+    """The whole pipeline on STRUCTURED shelf scenes with the detector whose head was fitted on such scenes (tests/golden/fitted_head.pt,
+    a test fixture): realistic proposals -- as many confident boxes as there are products, of the products' shapes -- instead of the
+    random-weight detector's 200 boxes of one shape.  Same gallery, same kernels; a side figure, never `value`."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import accuracy                                    # (only its fixture loader: nothing of the oracle is touched here)
+    if not os.path.exists(accuracy.FITTED_HEAD):
+        return None
+    from cvpce_amd import ops, production, synthetic
+    det = accuracy.fitted_detector(dpi, precision)[0].to(dev)
+    products = synthetic.product_images(1024, seed=200)
+    scenes = [synthetic.structured_shelf(i, image_size, image_size, products, pool=range(1000)) for i in range(ipg)]
+    images = [sc[0].to(dev) for sc in scenes]
+    pipe = production.BatchedPipeline(det, clf, 0.5)
+    for _ in range(3):
+        out = pipe.run(images)
+    t, _ = timed_windows(lambda: pipe.run(images), steps, 1, dev, collective=False)
+    ops.PROFILE = ops.ConvProfile()
+    out = pipe.run(images)
+    summ = ops.PROFILE.summary()
+    ops.PROFILE = None
+    counts = out['counts_host']
+    bx = torch.cat([out['boxes'][i, :counts[i]] for i in range(len(images))]).to(torch.long).float()
+    bw, bh = (bx[:, 2] - bx[:, 0]).clamp(min=1), (bx[:, 3] - bx[:, 1]).clamp(min=1)
+    emb = {k: v for k, v in summ.items() if k in ('vgg_stem2_kernel', 'conv3x3_halo3_kernel')}
+    return {'images': ipg, 'images_per_s': round(ipg * steps / t, 2), 'ms_per_step': round(t / steps * 1e3, 3), 'detector_precision': precision,
+            'confident_boxes_per_image': round(sum(counts) / len(counts), 1), 'products_per_image': round(sum(len(sc[1]) for sc in scenes) / len(scenes), 1),
+            'short_over_long_mean': round(float((torch.minimum(bw, bh) / torch.maximum(bw, bh)).mean()), 4), 'wide_fraction': round(float((bw > bh).float().mean()), 4),
+            'embed_stem_and_conv2_executed_over_algorithmic': round(sum(v['flops_executed'] for v in emb.values()) / max(1.0, sum(v['flops'] for v in emb.values())), 4),
+            'note': 'structured shelf scenes + the fitted detector head (test fixture): proposals of realistic count and shape; a side figure'}
 
 
 def embed_planted_boxes(dev, enc, image, n_boxes, seed=7, reps=5):
