@@ -37,6 +37,7 @@ FUSED_EMBED_BATCH = min(FUSED_EMBED_BATCH, FUSED_EMBED_MAX)        # (an over-la
 # with 0.5, so the part of the 256 x 256 embedder input below / right of the box content is the same constant in every crop; conv
 # tiles whose receptive field lies inside it are not computed (bit-identical results: tests/test_gpu_skip.py).  A/B switch.
 SKIP_PADDING = _os.environ.get('CVPCE_SKIP_PADDING', '1') != '0'
+LATE_EMBED_MAX = int(_os.environ.get('CVPCE_LATE_EMBED_MAX', 2000))   # crops per pass of the late layers (conv3_1 on) of the work-list schedule
 # ... and the LISTED tiles are cut at their last non-constant row (list entries carry `rows` in {4, 8, 12, 16}; the halo kernels stop
 # streaming patch rows there).  Pays since the work-list kernels take CONTIGUOUS blocks of the list (with the old strided
 # assignment a workgroup got nothing but cut tiles or nothing but full ones): same call, 29.15 / 29.41 -> 27.98 ms per 1 600
@@ -119,7 +120,7 @@ class MACVGGEngine:
             self.plan = self.plan[2:]
         self.device = device
         self.embedding_size = model.embedding_size
-        self._skip_plans = {}      # input size -> the work-list schedule of `_embed_pass_skip` (None: this plan has no such schedule)
+        self._skip_plans = {}      # input size -> the work-list schedule of `_embed_skip` (None: this plan has no such schedule)
         self._mac_tables = {}      # id of a constant crop -> per MAC layer, the row / column suffix maxima of the constant crop's map
         self._const_crops = {}     # (mean, std, channels, size) -> the all-padding crop
 
@@ -211,33 +212,67 @@ class MACVGGEngine:
         self._keep_const = getattr(self, '_keep_const', []) + [const_in]  # (the key holds a data pointer: keep the tensor alive)
         return tables
 
-    def _embed_pass_skip(self, xb, ext, const_in, sched):
-        """One pass of the schedule over work lists: xb (n,S,S,c) + the constant crop as image n -> MAC descriptor (n,1024)."""
+    def _embed_skip(self, x, ext, const_in, sched):
+        """The schedule over work lists: x (N,S,S,c) crops -> MAC descriptor (N,1024).  Two phases:
+          * EARLY layers (the stem and the Cout <= 128 convs, whose per-crop tensors are 2-4 MB) in passes of <= FUSED_EMBED_MAX images,
+            each with the constant crop as its last image; the last early layer of every pass writes straight into ONE tensor over
+            all crops, pass after pass, so that the constant crop of a pass is overwritten by the next pass's first crop and the
+            final tensor is [crop 0 .. crop N-1, constant crop];
+          * LATE layers (conv3_1 on: <= 2 MB per crop) in ONE pass over all N + 1 images: half as many launches, each with twice the
+            tiles per workgroup -- the uneven tail of a launch (workgroups run out of tiles a tile apart) costs half as much."""
         steps, layers, pool_mask = sched
-        n = xb.shape[0]
+        N, S, nl = x.shape[0], x.shape[1], len(steps)
+        early = 1 + sum(1 for st in steps[1:] if st[1].cout <= 128 and not st[3])
+        if any(st[1].cout <= 128 for st in steps[early:]):
+            early = nl                                     # (not the VGG16 shape: wide-tile layers after halo2 ones -- everything in passes)
+        dev = x.device
         mac_skips = any(st[3] and layers[i][-1] for i, st in enumerate(steps) if i)      # a MAC layer whose list leaves tiles / rows out
-        if mac_skips:
-            lists, counts, computed = ops.embed_worklists(ext, n + 1, xb.shape[1], pool_mask, layers, (xb.shape[1] // 16) ** 2, want_computed=True)
-            tables = self.mac_tables(const_in, sched)
-            desc = torch.empty((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
-            o = 0
-            for li, st in enumerate(steps):
-                if li and st[3]:
-                    ops.mac_init(desc, o, tables[li][0], tables[li][1], computed[li])
-                    o += st[1].cout
-        else:
-            lists, counts = ops.embed_worklists(ext, n + 1, xb.shape[1], pool_mask, layers, (xb.shape[1] // 16) ** 2)
-            desc = torch.zeros((n + 1, self.embedding_size), dtype=torch.float32, device=xb.device)
-        off = 0
-        t = ops.vgg_stem_list(xb, const_in, self.stem, lists[0], counts[0:1])
-        for li, (kind, pc, pool, mac, store) in enumerate(steps[1:], start=1):
-            nl = len(steps)
-            t = ops.conv2d_list(t, pc, lists[li], counts[li:li + 1], act=1, pool=pool, mac=desc if mac else None, mac_off=off, store=store,
-                                units=counts[nl + li:nl + li + 1],
-                                strips=(lists[nl + li], counts[2 * nl + li:2 * nl + li + 1]) if layers[li][-1] == 3 else None)
-            if mac:
-                off += pc.cout
-        return desc[:n]
+        tables = self.mac_tables(const_in, sched) if mac_skips else None
+
+        def run(t, ext_, first, last, n_img, out_last=None):
+            """steps[first:last] over n_img images (the constant crop last); the last of them writes into out_last if given."""
+            sub = layers[first:last]
+            k = last - first
+            res = ops.embed_worklists(ext_, n_img, S, pool_mask, sub, (S // 16) ** 2 if first == 0 else max(1, (sub[0][5] // 16)) ** 2,
+                                      want_computed=mac_skips)
+            lists, counts = res[0], res[1]
+            if mac_skips:
+                o = sum(st[1].cout for st in steps[1:first] if st[3])
+                for j in range(k):
+                    if steps[first + j][3] if first + j else False:
+                        ops.mac_init(desc, o, tables[first + j][0], tables[first + j][1], res[2][j])
+                        o += steps[first + j][1].cout
+            off = sum(st[1].cout for st in steps[1:first] if st[3])
+            for j in range(k):
+                li = first + j
+                if li == 0:
+                    t = ops.vgg_stem_list(t, const_in, self.stem, lists[0], counts[0:1])
+                    continue
+                kind, pc, pool, mac, store = steps[li]
+                t = ops.conv2d_list(t, pc, lists[j], counts[j:j + 1], act=1, pool=pool, mac=desc if mac else None, mac_off=off, store=store,
+                                    units=counts[k + j:k + j + 1], out=out_last if (j == k - 1 and store) else None,
+                                    strips=(lists[k + j], counts[2 * k + j:2 * k + j + 1]) if layers[li][-1] == 3 else None)
+                if mac:
+                    off += pc.cout
+            return t
+
+        desc = (torch.empty if mac_skips else torch.zeros)((N + 1, self.embedding_size), dtype=torch.float32, device=dev)
+        if early >= nl:                                     # everything in passes (each pass has its own descriptor rows)
+            outs = []
+            for s_, e_ in _passes(N, FUSED_EMBED_BATCH, FUSED_EMBED_MAX - 1):
+                desc = (torch.empty if mac_skips else torch.zeros)((e_ - s_ + 1, self.embedding_size), dtype=torch.float32, device=dev)
+                run(x[s_:e_], ext[s_:e_], 0, nl, e_ - s_ + 1)
+                outs.append(desc[:e_ - s_])
+            return torch.cat(outs)
+        eh, ec = layers[early - 1][0], steps[early - 1][1].cout if early > 1 else 64         # the last early layer's output: (eh, eh, ec) per image
+        big = torch.empty((N + 1, eh, eh, ec), dtype=torch.bfloat16, device=dev)
+        for s_, e_ in _passes(N, FUSED_EMBED_BATCH, FUSED_EMBED_MAX - 1):
+            if early == 1:                                  # (a plan whose first conv after the stem is already a late layer)
+                big[s_:e_ + 1].copy_(run(x[s_:e_], ext[s_:e_], 0, 1, e_ - s_ + 1))
+            else:
+                run(x[s_:e_], ext[s_:e_], 0, early, e_ - s_ + 1, out_last=big[s_:e_ + 1])
+        run(big, ext, early, nl, N + 1)
+        return desc[:N]
 
     def embed_packed(self, x, eps=1e-8, want_bf16=False, batch=None, ext=None, const_in=None):
         """x: (B,256,256,8) bf16, already normalised -> (B,1024) f32 unit-norm [, bf16 copy].
@@ -250,16 +285,19 @@ class MACVGGEngine:
         step = batch or (FUSED_EMBED_BATCH if fused else MAX_EMBED_BATCH)
         plan = self.plan + [('desc', None)]            # the second descriptor: amax of the last map (classification.py:48-49)
         sched = self.skip_plan(x.shape[1]) if (SKIP_PADDING and ext is not None and const_in is not None and fused and x.shape[1] == x.shape[2]) else None
-        for s, e in _passes(x.shape[0], step, (FUSED_EMBED_MAX - (1 if sched else 0)) if fused else step):
-            xb = x[s:e]
-            if sched is not None:
-                desc = self._embed_pass_skip(xb, ext[s:e], const_in, sched)
-                r = ops.l2_normalize(desc.contiguous(), eps, want_bf16)
+        if sched is not None and x.shape[0]:
+            # (the late layers' tensors: 64 x 64 x 256 per crop -> at most LATE_EMBED_MAX crops per call under the 32-bit tensor limits)
+            for s, e in _passes(x.shape[0], LATE_EMBED_MAX, LATE_EMBED_MAX):
+                r = ops.l2_normalize(self._embed_skip(x[s:e], ext[s:e], const_in, sched).contiguous(), eps, want_bf16)
                 if want_bf16:
                     outs.append(r[0]); outs_bf.append(r[1])
                 else:
                     outs.append(r)
-                continue
+            if want_bf16:
+                return torch.cat(outs), torch.cat(outs_bf)
+            return torch.cat(outs)
+        for s, e in _passes(x.shape[0], step, FUSED_EMBED_MAX if fused else step):
+            xb = x[s:e]
             desc = torch.zeros((xb.shape[0], self.embedding_size), dtype=torch.float32, device=x.device)   # (zeros: the fused MAC epilogue takes atomic maxima of values >= 0)
             off = 0
             if self.stem is not None:

@@ -434,11 +434,11 @@ def vgg_stem_list(x, const_in, ps, work, count, units=None):
     T.vgg_stem_fused_list(x, const_in, ps.w1, ps.b1, ps.w2, ps.b2, out, work, count)
     if prof is not None:
         e1.record()
-        prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n1 * h * w, e0, e1, count, ps.flops_per_pixel * 256))   # (the stem computes whole tiles)
+        prof.records.append(('vgg_stem2_kernel', ps.flops_per_pixel * n1 * h * w, e0, e1, count, ps.flops_per_pixel * 256, f'stem@{h}'))   # (the stem computes whole tiles)
     return out
 
 
-def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True, units=None, strips=None):
+def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, store=True, units=None, strips=None, out=None):
     """3x3 / s1 / p1 conv (+ReLU, + fused MaxPool2d(2,2), + fused MAC descriptor) over a work list; x (N,H,W,Cin) with the
     constant crop as image N - 1.  strips = (strip list, its count): a second launch computes the layer's strip list (tiles with
     only 4 useful rows, three at a time) into the same output.  Returns the output tensor (None with store=False)."""
@@ -446,9 +446,13 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
     assert x.dtype == BF16 and pc.dtype == BF16 and x.is_contiguous() and x.dim() == 4
     assert pc.cin_pad % 64 == 0 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and pc.cout % 8 == 0 and pc.cout > 64
     n, h, w, cin = x.shape
-    out = None
-    if store:
-        out = torch.empty((n, h // 2, w // 2, pc.cout) if pool else (n, h, w, pc.cout), dtype=BF16, device=x.device)
+    oshape = (n, h // 2, w // 2, pc.cout) if pool else (n, h, w, pc.cout)
+    if not store:
+        out = None
+    elif out is None:
+        out = torch.empty(oshape, dtype=BF16, device=x.device)
+    else:
+        assert tuple(out.shape) == oshape and out.dtype == BF16 and out.is_contiguous()
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -460,14 +464,14 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
         tile_flops = 2.0 * 16 * (32 if wide else 16) * pc.cout * 9 * pc.cin
         # (`units` counts the layer's whole MFMA work, its strip launch included: the strip record below carries none)
         prof.records.append(('conv3x3_halo3_kernel' if wide else 'conv3x3_halo2_kernel', 2.0 * (n - 1) * h * w * pc.cout * 9 * pc.cin, e0, e1)
-                            + ((units, tile_flops / 16) if units is not None else (count, tile_flops)))
+                            + ((units, tile_flops / 16) if units is not None else (count, tile_flops)) + (f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else ''),))
     if strips is not None:
         assert pc.cout > 128
         T.conv3x3_halo_strips(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
         if prof is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
-            prof.records.append(('conv3x3_halo2_kernel', 0.0, e1, e2, None, 0.0))
+            prof.records.append(('conv3x3_halo2_kernel', 0.0, e1, e2, None, 0.0, f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else '')))
     return out
 
 

@@ -218,7 +218,13 @@ def test_multi_pass_and_all_padding(cuda, skip_rows):
     ext = ops.crop_extents(boxes, None, h0, w0, S)
     assert ext[3].tolist() == [S, 0]                              # no content column: the whole crop is the constant
     const = eng.const_crop(C.TANH_MEAN, C.TANH_STD, 4, S)
-    assert torch.equal(eng.embed_packed(crops), eng.embed_packed(crops, ext=ext, const_in=const))
+    plain = eng.embed_packed(crops)
+    assert torch.equal(plain, eng.embed_packed(crops, ext=ext, const_in=const))      # two early passes (768 + 70 crops), one late pass over all
+    old, C.LATE_EMBED_MAX = C.LATE_EMBED_MAX, 500                                      # ... and with the late layers in two passes as well
+    try:
+        assert torch.equal(plain, eng.embed_packed(crops, ext=ext, const_in=const))
+    finally:
+        C.LATE_EMBED_MAX = old
 
 
 def test_pipeline_results_identical_with_and_without_skipping(cuda):

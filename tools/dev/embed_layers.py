@@ -37,17 +37,14 @@ for skip in (True, False):
     eng.embed_packed(crops, **kw)
     torch.cuda.synchronize()
     ops.PROFILE = None
-    names = ['stem', 'c2_1', 'c2_2', 'c3_1', 'c3_2', 'c3_3', 'c4_1', 'c4_2', 'c4_3', 'c5_1', 'c5_2', 'c5_3']
-    agg = {}
-    recs, li = [], -1
-    for rec in prof.records:                       # a layer's strip launch (a record without FLOPs of its own) is booked on the layer
-        li += 0 if (len(rec) > 4 and rec[4] is None) else 1
-        recs.append((li, rec))
-    for i, rec in recs:
-        nm = names[i % 12]
+    agg, order = {}, []
+    for i, rec in enumerate(prof.records):            # work-list records carry a tag (layer shape); plain ones are numbered
+        nm = rec[6] if len(rec) > 6 else f'launch{i % 12:02d}'
         ms = rec[2].elapsed_time(rec[3])
         exe = (float(rec[4].item()) * rec[5] if rec[4] is not None else 0.0) if len(rec) > 4 else rec[1]
+        if nm not in agg:
+            order.append(nm)
         a = agg.setdefault(nm, [0.0, 0.0, 0.0]); a[0] += ms; a[1] += rec[1]; a[2] += exe
-    for nm in names:
+    for nm in order:
         ms, alg, exe = agg[nm]
-        print(f'  {nm:5s} {ms:7.3f} ms  alg {alg / 1e12:6.2f} TF  exe {exe / 1e12:6.2f} TF ({exe / alg:5.2f})  {exe / ms / 1e9:7.1f} TFLOP/s executed')
+        print(f'  {nm:16s} {ms:7.3f} ms  alg {alg / 1e12:6.2f} TF  exe {exe / 1e12:6.2f} TF ({exe / max(alg, 1):5.2f})  {exe / ms / 1e9:7.1f} TFLOP/s executed')
