@@ -324,7 +324,8 @@ class BatchedPipeline:
 
     def _crops(self, images, det_out):
         """RoI crops of every image's confident boxes, launched WITHOUT knowing the counts on the host: the crop kernel reads
-        the boxes and the confidence-prefix count from device memory and skips the slots beyond it."""
+        the boxes and the confidence-prefix count from device memory and skips the slots beyond it.
+        -> (crops, their content extents | None, the encoder's all-padding crop | None)."""
         boxes, scores, labels, count, conf_count, gauss = det_out
         eng = self.detector.engine()
         emb_eng = self.classifier.encoder.engine()
@@ -344,12 +345,10 @@ class BatchedPipeline:
                             out=crops[i * dpi:(i + 1) * dpi])
             if skip:
                 ops.crop_extents(boxes[i], conf_count[i:i + 1], img.shape[1], img.shape[2], size, out=ext[i * dpi:(i + 1) * dpi])
-        self._ext = ext
-        self._const_in = emb_eng.const_crop(mean, std, crops.shape[3], size) if skip else None
-        return crops
+        return crops, ext, (emb_eng.const_crop(mean, std, crops.shape[3], size) if skip else None)
 
-    def _select(self, crops, counts):
-        """The embedder only runs over the valid crops (compaction = a gather of row indices)."""
+    def _select(self, crops, counts, ext=None):
+        """The embedder only runs over the valid crops (compaction = a gather of row indices; their extents go along)."""
         n, dpi = len(counts), self.detector.detections_per_img
         eng = self.detector.engine()
         if sum(counts) == n * dpi:
@@ -357,14 +356,14 @@ class BatchedPipeline:
         else:
             sel = torch.cat([torch.arange(i * dpi, i * dpi + c, device=eng.device) for i, c in enumerate(counts)])
             valid = crops.index_select(0, sel)
-            if self.__dict__.get('_ext') is not None:
-                self._ext = self._ext.index_select(0, sel)
-        return valid, sel
+            if ext is not None:
+                ext = ext.index_select(0, sel)
+        return valid, sel, ext
 
     def _crop_embed_match(self, images, det_out, counts, embed_batch=None):
         """(kept for the dev tools) crops + selection with counts already on the host."""
-        crops = self._crops(images, det_out)
-        valid, sel = self._select(crops, counts)
+        crops, ext, const_in = self._crops(images, det_out)
+        valid, sel, ext = self._select(crops, counts, ext)
         return crops, valid, sel
 
     def _finish(self, images, det_out, counts, emb, idx, sel):
@@ -408,13 +407,13 @@ class BatchedPipeline:
         pin[n].copy_(det_out[4], non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
-        crops = self._crops(images, det_out)
+        crops, ext, const_in = self._crops(images, det_out)
         copied.synchronize()
         counts = pin[n].tolist()
-        valid, sel = self._select(crops, counts)
+        valid, sel, ext = self._select(crops, counts, ext)
         t2 = mark()
-        if self.__dict__.get('_ext') is not None:
-            emb = self.classifier.encoder.engine().embed_packed(valid, ext=self._ext, const_in=self._const_in)
+        if ext is not None:         # (an encoder with the work-list schedule: the tiles in the crops' constant padding are skipped)
+            emb = self.classifier.encoder.engine().embed_packed(valid, ext=ext, const_in=const_in)
         else:
             emb = self.classifier.encoder.engine().embed_packed(valid)
         t3 = mark()
