@@ -48,8 +48,9 @@ class ProposalGenerator:
         boxes, scores, labels, count, conf, gauss = det.engine().detect([img], det.num_classes, det.detections_per_img, self.condfidence_threshold)
         det.backbone.gaussians = None
         dpi = boxes.shape[1]
-        host = torch.empty(dpi * 4 + 1, dtype=torch.float32).pin_memory() if self.__dict__.get('_pin') is None or self._pin.numel() != dpi * 4 + 1 else self._pin
-        self._pin = host
+        host = self.__dict__.get('_pin')                     # pinned staging buffer: dpi boxes + the prefix length, reused across calls
+        if host is None or host.numel() != dpi * 4 + 1:
+            host = self._pin = torch.empty(dpi * 4 + 1, dtype=torch.float32).pin_memory()
         packed = torch.cat((boxes[0].reshape(-1), conf[:1].to(torch.float32)))
         host.copy_(packed, non_blocking=True)
         torch.cuda.current_stream().synchronize()
