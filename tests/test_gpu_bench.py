@@ -42,6 +42,18 @@ def test_pipeline_line_small(cuda):
     assert d['parity']['by_precision']['fp16']['frac_oracle_boxes_iou90'] >= d['parity']['by_precision']['bf16']['frac_oracle_boxes_iou90']
     p = d['parity']
     assert p['images'] == 4 and 0.5 < p['ap50_vs_oracle'] <= 1.0 and abs(p['G256_bf16']['top1_acc_delta_pt']) <= 2.0
+    # round 4: the throughput in BOTH detector storage modes, executed vs algorithmic work, the fitted-detector parity against true boxes
+    v = d['value_by_detector_precision']
+    assert v['bf16'] > 0 and v['fp16'] > 0 and abs(v['bf16'] - d['value']) < 1e-6
+    g = r['gflop_per_step']
+    assert 0 < g['executed'] <= g['algorithmic'] and r['end_to_end']['executed_tflops'] <= r['end_to_end']['algorithmic_tflops']
+    assert 0 < r['crop_shapes']['short_over_long_mean'] <= 1
+    f = p['fitted_detector']
+    assert f['true_boxes'] > 50 and set(f['by_precision']) == {'bf16', 'fp16'}
+    assert f['by_precision']['fp16']['ap50_true_gt_oracle'] > 0.5 and abs(f['by_precision']['fp16']['map_delta_pt_true_gt']) <= 1.0
+    e = w['embed_planted_boxes']
+    assert e['embed_ms_with_skipping'] < e['embed_ms_without'] and 0 < e['executed_over_algorithmic_flops'] < 1
+    assert w['pipeline_fitted_scenes']['images_per_s'] > 0 and w['pipeline_fitted_scenes']['confident_boxes_per_image'] > 5
 
 
 def test_detector_and_match_stress_lines(cuda):
