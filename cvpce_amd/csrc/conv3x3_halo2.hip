@@ -350,9 +350,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     }
     // rows 0..15 of step T: prefetch row P + 2, compute row P
 #define G2_RP(T, P) G2_READ(T, (P) + 2) G2_ROW(T, P)
-#define G2_ROWS_0_15(T)                                                                                        \
-    G2_RP(T, 0) G2_RP(T, 1) G2_RP(T, 2) G2_RP(T, 3) G2_RP(T, 4) G2_RP(T, 5) G2_RP(T, 6) G2_RP(T, 7)            \
-    G2_RP(T, 8) G2_RP(T, 9) G2_RP(T, 10) G2_RP(T, 11) G2_RP(T, 12) G2_RP(T, 13) G2_RP(T, 14) G2_RP(T, 15)
     // the chunk hand-off: this wave is done with the PREVIOUS chunk's buffer and (vmcnt) its own pieces of the NEXT chunk's
     // patch have landed -- at most the 6 weight loads just issued are younger than those pieces; then the DMA of the chunk
     // after the next one goes into the buffer the previous chunk used
@@ -582,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
 #endif
 #undef G2_STEP
 #undef G2_HANDOFF
-#undef G2_ROWS_0_15
+#undef G2_ROWS_AND_TAIL
 #undef G2_RP
 #undef G2_ROW
 #undef G2_ROW_KH

@@ -242,9 +242,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 #define G3_RP(T, P) G3_READ(T, (P) + 2) G3_ROW(T, P)
-#define G3_ROWS_0_15(T)                                                                                        \
-    G3_RP(T, 0) G3_RP(T, 1) G3_RP(T, 2) G3_RP(T, 3) G3_RP(T, 4) G3_RP(T, 5) G3_RP(T, 6) G3_RP(T, 7)            \
-    G3_RP(T, 8) G3_RP(T, 9) G3_RP(T, 10) G3_RP(T, 11) G3_RP(T, 12) G3_RP(T, 13) G3_RP(T, 14) G3_RP(T, 15)
     // step inside a sub-chunk (T = 0, 1, 3, 4): fetch the next step's weights, stream the rows; rows 16, 17 prefetch
     // rows 0, 1 of step T + 1 from the same buffer
     // the sub-chunk hand-off: this wave is done with the PREVIOUS sub-chunk's buffer and (vmcnt) its own pieces of the NEXT
@@ -419,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #undef G3_STEP_HANDOFF
 #undef G3_STEP
 #undef G3_HANDOFF
-#undef G3_ROWS_0_15
+#undef G3_ROWS_AND_TAIL
 #undef G3_RP
 #undef G3_ROW
 #undef G3_READ

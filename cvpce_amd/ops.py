@@ -421,7 +421,7 @@ def mac_init(desc, off, row_suffix_max, col_suffix_max, computed):
     T.mac_init(desc, int(off), row_suffix_max, col_suffix_max, computed)
 
 
-def vgg_stem_list(x, const_in, ps, work, count, units=None):
+def vgg_stem_list(x, const_in, ps, work, count):
     """`vgg_stem` over a work list: x (N-1,H,W,4|8) + the constant crop const_in (H,W,c) -> (N,H/2,W/2,64)."""
     _need_cuda(x, const_in, work, count)
     assert x.dtype == BF16 and x.is_contiguous() and x.shape[3] in (4, 8) and const_in.is_contiguous()
