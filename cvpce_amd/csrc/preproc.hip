@@ -307,12 +307,14 @@ extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int
 // Content extent of every crop at the crop resolution S (the embedder's constant-padding tile skipping, skiplist.hip):
 // ext[p] = (rows, cols) such that every output pixel with oy >= rows or ox >= cols is exactly the pad constant -- the predicate
 // under which crop_resize*_kernel writes the constant, evaluated with the same src_index.  Boxes beyond *count: (S, S).
-__global__ void crop_extents_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int max_boxes, int H0, int W0,
-                                    int S, int* __restrict__ ext) {
+__global__ void crop_extents_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int max_boxes, int per_image, int H0,
+                                    int W0, int S, int* __restrict__ ext) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= max_boxes) return;
     int ey = S, ex = S;
-    if (!count || p < *count) {
+    // per_image > 0: the boxes of several images of one size, `per_image` slots each, one count per image
+    const bool live = !count || (per_image > 0 ? (p % per_image) < count[p / per_image] : p < *count);
+    if (live) {
         const float* b = boxes + (size_t)p * 4;
         long long x1 = (long long)b[0], y1 = (long long)b[1], x2 = (long long)b[2], y2 = (long long)b[3];
         x1 = x1 < 0 ? 0 : (x1 > W0 ? W0 : x1);
@@ -323,30 +325,37 @@ __global__ void crop_extents_kernel(const float* __restrict__ boxes, const int* 
         if (cw < 0) cw = 0;
         if (ch < 0) ch = 0;
         const int larger = cw > ch ? cw : ch;
+        ey = ex = 0;                                         // (degenerate box: the whole crop is the constant)
         if (larger > 0) {
             const float sc = (float)larger / (float)S;
-            ey = ex = 0;
-            for (int o = 0; o < S; ++o) {                    // the first source index is monotone in o: count the content rows / columns
-                int i0, i1;
-                float l0, l1;
-                src_index(sc, o, larger, i0, i1, l0, l1);
-                if (i0 < ch) ey = o + 1;
-                if (i0 < cw) ex = o + 1;
-            }
-        } else {
-            ey = ex = 0;                                     // degenerate box: the whole crop is the constant
+            // the first source index of output row / column o is monotone in o (fp32 rounding is monotone): the number of o with
+            // index < limit is the first o whose index reaches it -- a bisection instead of a scan of all S positions
+            auto first_at_least = [&](int limit) {
+                int lo = 0, hi = S;                          // answer in [lo, hi]
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    int i0, i1;
+                    float l0, l1;
+                    src_index(sc, mid, larger, i0, i1, l0, l1);
+                    if (i0 < limit) lo = mid + 1; else hi = mid;
+                }
+                return lo;
+            };
+            ey = first_at_least(ch);
+            ex = first_at_least(cw);
         }
     }
     ext[2 * p] = ey;
     ext[2 * p + 1] = ex;
 }
 
-extern "C" int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int H0, int W0, int S, int* ext_out,
-                                  void* stream) {
-    if (!boxes || !ext_out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
+extern "C" int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int boxes_per_image, int H0, int W0, int S,
+                                  int* ext_out, void* stream) {
+    if (!boxes || !ext_out || S <= 0 || H0 <= 0 || W0 <= 0 || boxes_per_image < 0) return CVPCE_ERR_ARG;
     if (max_boxes <= 0) return CVPCE_OK;
+    if (boxes_per_image > 0 && max_boxes % boxes_per_image != 0) return CVPCE_ERR_ARG;
     hipLaunchKernelGGL(crop_extents_kernel, dim3((max_boxes + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, count_dev, max_boxes,
-                       H0, W0, S, ext_out);
+                       boxes_per_image, H0, W0, S, ext_out);
     return cvpce_check_launch();
 }
 

@@ -43,7 +43,9 @@ __device__ __forceinline__ int skl_extent(int e0, int S, unsigned pool_mask, int
 }
 
 __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
-    __shared__ int s_cnt[1024];
+    __shared__ int s_cnt[1024];                        // scan scratch
+    __shared__ int s_end[1024], s_send[1024];          // per crop of the current chunk: END offset of its entries in the chunk's list / strip list
+    __shared__ unsigned s_geo[1024], s_ext[1024];      // (ny << 16 | nx << 8 | rows of the last tile row), (ey_in << 12 | ex_in)
     __shared__ int s_base, s_sbase, s_units;
     const cvpce_skip_layer L = a.L[blockIdx.x];
     const int tid = threadIdx.x;
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
     unsigned long long* slist = a.lists + (long long)(a.nl + blockIdx.x) * a.stride;     // the layer's strip list (skip == 3)
     if (tid == 0) s_base = s_sbase = s_units = 0;
     __syncthreads();
-    // exclusive scan of one value per thread over the 1024 slots (Hillis-Steele) -> (this thread's offset, the total)
-    auto scan = [&](int v, int& total) {
+    // inclusive scan of one value per thread over the 1024 slots (Hillis-Steele), left in s_cnt
+    auto scan = [&](int v) {
         s_cnt[tid] = v;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -62,10 +64,6 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
             s_cnt[tid] += t;
             __syncthreads();
         }
-        const int off = s_cnt[tid] - v;
-        total = s_cnt[1023];
-        __syncthreads();
-        return off;
     };
     for (int n0 = 0; n0 < a.n; n0 += 1024) {
         const int n = n0 + tid;
@@ -90,6 +88,7 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
             eiy = skl_extent(ey0, a.S, a.pool_mask, L.in_ops, L.in_H);
             eix = skl_extent(ex0, a.S, a.pool_mask, L.in_ops, L.in_W);
         }
+        if (nx == 0) ny = 0;
         // a last tile row with 4 useful rows goes to the strip list (three such tiles are computed as one, conv3x3_halo2.hip STRIP)
         const bool strips = L.skip >= 3 && ny > 0 && last_rows == 4;
         const int scnt = strips ? nx : 0, cnt = ny * nx - scnt;
@@ -98,37 +97,55 @@ __global__ __launch_bounds__(1024) void embed_worklists_kernel(WorklistArgs a) {
             a.computed[((long long)blockIdx.x * a.n + n) * 2] = ny > 0 ? (ny - 1) * 16 + last_rows : 0;
             a.computed[((long long)blockIdx.x * a.n + n) * 2 + 1] = nx;
         }
-        int total, stotal;
+        // MFMA work of this crop's tiles in sixteenths of a tile: full tiles 16, a tile cut at `rows` rows + 1 (it streams patch rows
+        // 0 .. rows + 1), a strip 4 (three strips share one pass of 72 MFMAs per step against a full tile's 96)
+        if (ny > 0) atomicAdd(&s_units, nx * (16 * (ny - 1) + (strips ? 4 : (last_rows < 16 ? last_rows + 1 : 16))));
+        s_geo[tid] = ((unsigned)ny << 16) | ((unsigned)nx << 8) | (unsigned)last_rows;
+        s_ext[tid] = ((unsigned)eiy << 12) | (unsigned)eix;
         const int base0 = s_base, sbase0 = s_sbase;          // (read before the scans' barriers; updated behind them)
-        const int base = base0 + scan(cnt, total);
-        const int sbase = sbase0 + scan(scnt, stotal);
-        if (tid == 0) { s_base = base0 + total; s_sbase = sbase0 + stotal; }
-        // entries of this thread's crop; blockIdx.y splits the crops among workgroups (every workgroup runs the same scans)
-        if (n < a.n && (n % (int)gridDim.y) == (int)blockIdx.y) {
-            const unsigned ext = ((unsigned)eiy << 12) | (unsigned)eix;
-            int units = 0;
-            for (int j = 0; j < cnt + scnt; ++j) {
-                const int ty = j / nx, tx = j - ty * nx;
-                const int rows = (ty == ny - 1) ? last_rows : 16;
-                const unsigned long long e = ((unsigned long long)(((unsigned)rows << 24) | ext) << 32) |
-                                             (unsigned long long)(((unsigned)n << 16) | ((unsigned)ty << 8) | (unsigned)tx);
-                if (j < cnt) {
-                    list[base + j] = e;
-                    units += rows < 16 ? rows + 1 : 16;      // a tile cut at `rows` streams patch rows 0 .. rows + 1: (rows + 1) / 16 of its MFMAs
-                } else {
-                    slist[sbase + j - cnt] = e;
-                    units += 4;                              // three strips share one pass of 72 MFMAs per step (a full tile: 96)
-                }
+        scan(cnt);
+        s_end[tid] = s_cnt[tid];
+        const int total = s_cnt[1023];
+        __syncthreads();
+        scan(scnt);
+        s_send[tid] = s_cnt[tid];
+        const int stotal = s_cnt[1023];
+        __syncthreads();
+        // the chunk's entries, one per thread and trip, coalesced; blockIdx.y splits them among the layer's workgroups (every
+        // workgroup runs the same scans).  entry e belongs to the first crop whose END offset exceeds e.
+        auto crop_of = [&](const int* ends, int e) {
+            int lo = 0, hi = 1023;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ends[mid] > e) hi = mid; else lo = mid + 1;
             }
-            atomicAdd(&s_units, units);
+            return lo;
+        };
+        for (int e = (int)blockIdx.y * 1024 + tid; e < total; e += (int)gridDim.y * 1024) {
+            const int c = crop_of(s_end, e);
+            const unsigned geo = s_geo[c];
+            const int cny = (int)(geo >> 16), cnx = (int)((geo >> 8) & 0xFF), j = e - (c ? s_end[c - 1] : 0);
+            const int ty = j / cnx, tx = j - ty * cnx;
+            const unsigned rows = (ty == cny - 1) ? (geo & 0xFF) : 16u;
+            list[base0 + e] = ((unsigned long long)((rows << 24) | s_ext[c]) << 32) |
+                              (unsigned long long)(((unsigned)(n0 + c) << 16) | ((unsigned)ty << 8) | (unsigned)tx);
         }
+        for (int e = (int)blockIdx.y * 1024 + tid; e < stotal; e += (int)gridDim.y * 1024) {
+            const int c = crop_of(s_send, e);
+            const unsigned geo = s_geo[c];
+            const int cny = (int)(geo >> 16), tx = e - (c ? s_send[c - 1] : 0);
+            slist[sbase0 + e] = ((unsigned long long)((4u << 24) | s_ext[c]) << 32) |
+                                (unsigned long long)(((unsigned)(n0 + c) << 16) | ((unsigned)(cny - 1) << 8) | (unsigned)tx);
+        }
+        __syncthreads();
+        if (tid == 0) { s_base = base0 + total; s_sbase = sbase0 + stotal; }
         __syncthreads();
     }
     if (tid == 0 && blockIdx.y == 0) {
         a.counts[blockIdx.x] = s_base;
+        a.counts[a.nl + blockIdx.x] = s_units;
         a.counts[2 * a.nl + blockIdx.x] = s_sbase;
     }
-    if (tid == 0) atomicAdd(&a.counts[a.nl + blockIdx.x], s_units);       // (summed over the workgroups that split the crops; zeroed by the host wrapper)
 }
 
 extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsigned pool_mask, const cvpce_skip_layer* layers, int n_layers,
@@ -147,7 +164,6 @@ extern "C" int cvpce_embed_worklists(const int* ext0, int n_images, int S, unsig
         a.L[i] = l;
     }
     const int split = n_images >= 64 ? 8 : 1;
-    if (hipMemsetAsync(counts + n_layers, 0, sizeof(int) * n_layers, (hipStream_t)stream) != hipSuccess) return CVPCE_ERR_LAUNCH;
     hipLaunchKernelGGL(embed_worklists_kernel, dim3(n_layers, split), dim3(1024), 0, (hipStream_t)stream, a);
     return cvpce_check_launch();
 }

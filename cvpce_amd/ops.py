@@ -377,14 +377,15 @@ def vgg_stem(x, ps):
 # ---------------------------------------------------------------------------
 # constant-padding tile skipping of the embedder (csrc/skiplist.hip; include/cvpce_amd.h)
 # ---------------------------------------------------------------------------
-def crop_extents(boxes, count, h0, w0, size=256, out=None):
+def crop_extents(boxes, count, h0, w0, size=256, out=None, per_image=0):
     """boxes (P,4) f32 device [+ count (1,) int32 device] -> (P,2) int32: content rows / columns of every crop that
-    `crop_resize` makes of them; pixels beyond are exactly the pad constant."""
+    `crop_resize` makes of them; pixels beyond are exactly the pad constant.  per_image > 0: the slots of several images of one
+    size (per_image each) with one count per image, in one launch."""
     _need_cuda(boxes, count)
     boxes = boxes.to(torch.float32).contiguous()
     if out is None:
         out = torch.empty((boxes.shape[0], 2), dtype=torch.int32, device=boxes.device)
-    T.crop_extents(boxes, count, int(h0), int(w0), int(size), out)
+    T.crop_extents(boxes, count, int(per_image), int(h0), int(w0), int(size), out)
     return out
 
 

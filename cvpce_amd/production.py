@@ -341,11 +341,14 @@ class BatchedPipeline:
         # skips the tiles that lie in it) -- only for an encoder whose engine has the work-list schedule
         skip = hasattr(emb_eng, 'skip_plan') and emb_eng.skip_plan(size) is not None
         ext = torch.empty((n * dpi, 2), dtype=torch.int32, device=eng.device) if skip else None
+        same_size = all(img.shape == images[0].shape for img in images)
         for i, img in enumerate(images):
             ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=mean, std=std, count=conf_count[i:i + 1],
                             out=crops[i * dpi:(i + 1) * dpi])
-            if skip:
+            if skip and not same_size:
                 ops.crop_extents(boxes[i], conf_count[i:i + 1], img.shape[1], img.shape[2], size, out=ext[i * dpi:(i + 1) * dpi])
+        if skip and same_size:                   # (images of one size: the extents of the whole batch in one launch)
+            ops.crop_extents(boxes.reshape(n * dpi, 4), conf_count, images[0].shape[1], images[0].shape[2], size, out=ext, per_image=dpi)
         return crops, ext, (emb_eng.const_crop(mean, std, crops.shape[3], size) if skip else None)
 
     def _select(self, crops, counts, ext=None):

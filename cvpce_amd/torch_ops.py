@@ -173,11 +173,12 @@ def _crop_resize(img, boxes, count, out, size, mode, mean, std):
                                 _stream()), 'crop_resize')
 
 
-@_op('crop_extents(Tensor boxes, Tensor? count, int h0, int w0, int size, Tensor(a!) ext) -> ()')
-def _crop_extents(boxes, count, h0, w0, size, ext):
-    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or ext.dtype != torch.int32 or not ext.is_contiguous() or ext.numel() < 2 * boxes.shape[0]:
-        raise RuntimeError('crop_extents: boxes (P,4) float32, ext (P,2) int32, both contiguous')
-    check(lib.cvpce_crop_extents(_p(boxes), _p(count), boxes.shape[0], h0, w0, size, _p(ext), _stream()), 'cvpce_crop_extents')
+@_op('crop_extents(Tensor boxes, Tensor? count, int per_image, int h0, int w0, int size, Tensor(a!) ext) -> ()')
+def _crop_extents(boxes, count, per_image, h0, w0, size, ext):
+    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or ext.dtype != torch.int32 or not ext.is_contiguous() or ext.numel() < 2 * boxes.shape[0] \
+            or (per_image > 0 and (count is None or count.numel() * per_image < boxes.shape[0])):
+        raise RuntimeError('crop_extents: boxes (P,4) float32, ext (P,2) int32, both contiguous; per_image > 0 needs one count per image')
+    check(lib.cvpce_crop_extents(_p(boxes), _p(count), boxes.shape[0], per_image, h0, w0, size, _p(ext), _stream()), 'cvpce_crop_extents')
 
 
 @_op('pad_extents(Tensor images, float pad, Tensor(a!) ext) -> ()')

@@ -168,9 +168,11 @@ int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int t
  * same tile position from the same operand bits as the constant crop's pixel.
  *
  * cvpce_crop_extents: ext_out[p] = (rows, cols) int32 pair per box, the content extent of crop p at the crop resolution S:
- * cvpce_crop_resize writes EXACTLY the pad constant to every pixel with oy >= rows or ox >= cols.  p >= *count_dev: (S, S). */
-int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int H0, int W0, int S, int* ext_out,
-                       void* stream);
+ * cvpce_crop_resize writes EXACTLY the pad constant to every pixel with oy >= rows or ox >= cols.  p >= *count_dev: (S, S).
+ * boxes_per_image > 0: `boxes` holds the slots of several images of ONE size (boxes_per_image each) and count_dev one count per
+ * image -- the whole batch in one launch. */
+int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int boxes_per_image, int H0, int W0, int S,
+                       int* ext_out, void* stream);
 /* The same extents read off crops that already exist as (B,3,S,S) f32 tensors (the input of Classifier.classify,
  * production.py:57-74): every pixel with y >= rows or x >= cols equals `pad` (0.5) in all three channels.  Data-driven: a tensor
  * without constant borders gets (S, S). */

@@ -90,6 +90,9 @@ def test_crop_extents_and_exact_padding(cuda):
     cnt = torch.tensor([5], dtype=torch.int32).cuda()
     e2 = ops.crop_extents(boxes.cuda(), cnt, h0, w0, S).cpu()
     assert torch.equal(e2[:5], ext[:5]) and (e2[5:] == S).all()
+    # ... and the slots of several images of one size in one launch (35 slots each, one count per image)
+    e3 = ops.crop_extents(boxes.cuda(), torch.tensor([35, 6], dtype=torch.int32).cuda(), h0, w0, S, per_image=35).cpu()
+    assert torch.equal(e3[:41], ext[:41]) and (e3[41:] == S).all()
 
 
 def _extent(e0, pool_mask, nops, size):
