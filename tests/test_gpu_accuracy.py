@@ -124,5 +124,6 @@ def test_fitted_pipeline_top1_against_true_products(fitted):
             assert v['n'] >= 50 and v['top1_acc_oracle'] >= 0.6, (prec, key, v)
             assert abs(v['delta_pt']) <= 100.0 / v['n'] + 1e-6, (prec, key, v)
             assert m['top1_agree'] >= (0.93 if prec == 'fp16' else 0.9), (prec, key, m)
-    for key, m in fitted['matching'].items():                          # the true boxes cropped and matched by both paths
-        assert abs(m['gt_boxes']['delta_pt']) <= 1.1 and m['gt_boxes']['top1_agree'] >= 0.98, (key, m['gt_boxes'])
+    for key, m in fitted['matching'].items():                          # the true boxes cropped and matched by both paths:
+        # top-1 accuracy against the pasted product's id within 0.1 pt (measured 0.0 here; 0.00 / +-0.02 pt on 4 096 crops at full size)
+        assert abs(m['gt_boxes']['delta_pt']) <= 0.1 and m['gt_boxes']['top1_agree'] >= 0.98, (key, m['gt_boxes'])
