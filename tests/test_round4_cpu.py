@@ -1,4 +1,4 @@
-"""Host logic of the embedder's constant-padding work lists (cvpce_amd/models/classification.py `MACVGGEngine.skip_plan`,
+"""Round-4 host logic on the CPU: the embedder's constant-padding work lists (cvpce_amd/models/classification.py `MACVGGEngine.skip_plan`,
 include/cvpce_amd.h `cvpce_skip_layer`), checked WITHOUT a GPU:
 
 * the schedule of VGG16 cfg 'D' (`/root/reference/cvpce/models/classification.py:27-37`: conv / ReLU / MaxPool2d stack up to
@@ -82,3 +82,26 @@ def test_extent_rule_matches_a_brute_force_experiment():
                 assert not torch.equal(t[..., ey - 1, :], c[..., ey - 1, :]), (ey0, k)
             if 0 < ex < size:
                 assert not torch.equal(t[..., :, ex - 1], c[..., :, ex - 1]), (ex0, k)
+
+
+def test_fitted_head_fixture_detects_products_in_the_oracle():
+    """tests/golden/fitted_head.pt (made by tests/golden/fit_head.py) over the seeded base: the fp32 ORACLE finds the pasted products
+    of unseen structured scenes -- the premise of the accuracy tests that read mAP against true boxes (tests/test_gpu_accuracy.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import accuracy
+    from cvpce_amd import metrics, synthetic
+    from oracle import gln as og
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    det, sd, recipe = accuracy.fitted_detector(200)
+    assert recipe['residual_gain'] == 0.25 and len(recipe['fit_keys']) == 10
+    # reference-format keys (proposals.py:162-168 via torchvision RetinaNetHead), all towers + the two output convs
+    assert all(k.startswith('head.classification_head.') or k.startswith('head.regression_head.') for k in recipe['fit_keys'])
+    products = synthetic.product_images(128, seed=200)
+    scenes = [synthetic.structured_shelf(i, 1024, 1024, products) for i in range(2)]
+    res = [og.gln_forward([sc[0]], sd, detections_per_img=200)[0] for sc in scenes]
+    m = metrics.calculate_metrics([sc[1] for sc in scenes], [r['boxes'] for r in res], [r['scores'] for r in res], iou_thresholds=(0.5,))[0.5]
+    assert float(m['ap']) >= 0.7 and float(m['ar_300']) >= 0.9, m
+    conf = [int((r['scores'] > 0.5).sum()) for r in res]
+    assert all(0.5 * len(sc[1]) <= c <= 3 * len(sc[1]) for c, sc in zip(conf, scenes)), (conf, [len(sc[1]) for sc in scenes])   # a bimodal score field
