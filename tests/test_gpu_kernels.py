@@ -223,24 +223,31 @@ def test_crop_resize_parity(cuda):
     assert (out[2:] == 5).all() and torch.equal(out[:2].float().cpu(), packed[:2])
 
 
-def _random_head_outputs(n, grids, a, k, seed, spread=2.0, bias=-1.0):
+def _random_head_outputs(n, grids, a, k, seed, spread=2.0, bias=-1.0, quantum=0.0):
     g = torch.Generator().manual_seed(seed)
     cls = [torch.randn(n, gh * gw * a * k, generator=g) * spread + bias for gh, gw in grids]
+    if quantum:                        # logits on a coarse grid: thousands of exact ties at the top-k cut and in the NMS order
+        cls = [torch.round(c / quantum) * quantum for c in cls]
     reg = [torch.randn(n, gh * gw * a, 4, generator=g) * 0.5 for gh, gw in grids]
     return cls, reg
 
 
-@pytest.mark.parametrize('dpi,seed,bias,k', [(1000, 0, -1.0, 1), (200, 1, 1.0, 1), (300, 2, -4.5, 1), (300, 3, -1.0, 3), (1000, 4, 0.5, 2)])
-def test_detect_postprocess_parity(cuda, dpi, seed, bias, k):
+@pytest.mark.parametrize('dpi,seed,bias,k,quantum', [(1000, 0, -1.0, 1, 0), (200, 1, 1.0, 1, 0), (300, 2, -4.5, 1, 0), (300, 3, -1.0, 3, 0),
+                                                     (1000, 4, 0.5, 2, 0), (300, 5, 0.0, 1, 0.5), (1000, 6, -3.0, 1, 0.125),
+                                                     (300, 7, -1.0, 3, 0.25)])
+def test_detect_postprocess_parity(cuda, dpi, seed, bias, k, quantum, monkeypatch):
     """K6-K8 against the oracle on identical fp32 logits: kept sets and order identical; k > 1 classes exercise the
-    per-class offsets of batched_nms and the anchor / label split of the flat candidate index."""
+    per-class offsets of batched_nms and the anchor / label split of the flat candidate index (and, at k = 3, a P3 level of
+    280 800 logits = 35 chunks: the one-kernel decode); quantum > 0 puts the logits on a grid, so that the top-k cut of a
+    level and of its chunks falls inside a run of equal logits (lowest index first) and the score threshold on exact values.
+    Every case also runs through the one-kernel decode: identical outputs."""
     from cvpce_amd import ops
     from cvpce_amd.models import proposals as P
     from oracle import gln as og
     n = 2
     padded = (800, 832)
     grids = [(100, 104), (50, 52), (25, 26), (13, 13), (7, 7)]
-    cls, reg = _random_head_outputs(n, grids, 9, k, seed, bias=bias)
+    cls, reg = _random_head_outputs(n, grids, 9, k, seed, bias=bias, quantum=quantum)
     resized = [(800, 810), (790, 832)]
     original = [(2048, 2073), (1000, 1053)]
     anchors = og.grid_anchors(padded, grids)
@@ -266,6 +273,82 @@ def test_detect_postprocess_parity(cuda, dpi, seed, bias, k):
         assert k == 1 or len(set(l.tolist())) == k
         assert int(conf[i]) == int((s > 0.5).sum())
         assert (scores[i, :c - 1] >= scores[i, 1:c]).all()
+    monkeypatch.setenv('CVPCE_DECODE_ONE_KERNEL', '1')
+    one = ops.detect_postprocess(
+        [c.to(cuda) for c in cls], [r.to(cuda) for r in reg], grids, strides, base.to(cuda), image_hw.to(cuda),
+        ratios.to(cuda), 9, k, og.TOPK_CANDIDATES, og.SCORE_THRESH, og.NMS_THRESH, og.BBOX_XFORM_CLIP, dpi, 0.5)
+    for x, y in zip(one, (boxes, scores, labels, count, conf)):
+        assert torch.equal(x, y)
+
+
+def test_detect_score_threshold_band(cuda, monkeypatch):
+    """The chunked decode decides sigmoid(l) > thresh from the logit alone outside a narrow band around logit(thresh) and
+    evaluates the sigmoid inside it; the one-kernel decode evaluates it for every logit.  Logits packed at 1-ulp and at
+    1e-4 steps around logit(thresh), for several thresholds (incl. one outside the range where the shortcut is enabled):
+    the two forms keep exactly the same candidates."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    from oracle import gln as og
+    grids = [(10, 10)]
+    for thresh in (0.05, 0.3, 0.5, 0.9, 0.995, 1e-7):
+        t = math.log(thresh / (1 - thresh))
+        t32 = torch.tensor(t, dtype=torch.float32)
+        fine = t32 + torch.arange(-225, 225, dtype=torch.float32) * torch.finfo(torch.float32).eps * max(abs(t), 1e-3)
+        coarse = t32 + torch.arange(-225, 225, dtype=torch.float32) * 1e-4 * (1 + abs(t))
+        lg = torch.cat([fine, coarse])[torch.randperm(900, generator=torch.Generator().manual_seed(1))].view(1, 900)
+        reg = torch.zeros(1, 900, 4)
+        args = ([lg.to(cuda)], [reg.to(cuda)], grids, [(8, 8)], P._base_anchors()[:1].contiguous().to(cuda),
+                torch.tensor([[80, 80]], dtype=torch.int32).to(cuda), torch.ones(1, 2).to(cuda), 9, 1, 1000, thresh, 2.0,
+                og.BBOX_XFORM_CLIP, 1000, 0.5)          # nms_thresh 2: nothing is suppressed, every candidate comes out
+        monkeypatch.delenv('CVPCE_DECODE_ONE_KERNEL', raising=False)
+        got = ops.detect_postprocess(*args)
+        monkeypatch.setenv('CVPCE_DECODE_ONE_KERNEL', '1')
+        one = ops.detect_postprocess(*args)
+        monkeypatch.delenv('CVPCE_DECODE_ONE_KERNEL')
+        assert 200 < int(got[3][0]) < 700, (thresh, int(got[3][0]))
+        for x, y in zip(got, one):
+            assert torch.equal(x, y), thresh
+        ref = int((torch.sigmoid(lg) > thresh).sum())
+        assert abs(int(got[3][0]) - ref) <= 8, (thresh, int(got[3][0]), ref)   # (torch's CPU sigmoid may differ by an ulp at the cut)
+
+
+def test_detect_nms_second_phase(cuda, monkeypatch):
+    """NMS runs on the first 8 x detections_per_img candidates first and on all of them only for the images that did not fill
+    up there.  A low IoU threshold suppresses so much that image 0 needs its remaining candidates (fewer than dpi boxes are
+    kept out of > limit candidates), while image 1 -- few candidates -- is final after phase 1: both equal the oracle and the
+    one-phase run."""
+    from cvpce_amd import ops
+    from cvpce_amd.models import proposals as P
+    from oracle import gln as og
+    n, dpi, nms_thresh = 2, 150, 0.02
+    padded = (800, 800)
+    grids = [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)]
+    cls, reg = _random_head_outputs(n, grids, 9, 1, 21, bias=0.0)
+    for c, r in zip(cls, reg):
+        c[1] -= 9.0                                         # image 1: about a hundred candidates in all
+        r[0, :, 2:] += 3.0                                  # image 0: boxes 20 x their anchors -- nearly all overlap
+    resized = [(800, 800), (800, 800)]
+    anchors = og.grid_anchors(padded, grids)
+    strides = [(padded[0] // gh, padded[1] // gw) for gh, gw in grids]
+    base = P._base_anchors()
+    args = ([c.to(cuda) for c in cls], [r.to(cuda) for r in reg], grids, strides, base.to(cuda),
+            torch.tensor(resized, dtype=torch.int32).to(cuda), torch.ones(n, 2).to(cuda), 9, 1, og.TOPK_CANDIDATES, og.SCORE_THRESH,
+            nms_thresh, og.BBOX_XFORM_CLIP, dpi, 0.5)
+    got = ops.detect_postprocess(*args)
+    monkeypatch.setenv('CVPCE_NMS_ONE_PHASE', '1')
+    one = ops.detect_postprocess(*args)
+    for x, y in zip(got, one):
+        assert torch.equal(x, y)
+    boxes, scores, labels, count, conf = got
+    ncand = [sum(min(1000, int((torch.sigmoid(c[i]) > og.SCORE_THRESH).sum())) for c in cls) for i in range(n)]
+    assert ncand[0] > 8 * dpi and int(count[0]) < dpi, (ncand, count.tolist())       # image 0 cannot be decided in phase 1
+    assert ncand[1] <= 8 * dpi and 0 < int(count[1]) < dpi, (ncand, count.tolist())
+    for i in range(n):
+        b, s, l = og.postprocess_image([c[i].view(-1, 1) for c in cls], [r[i] for r in reg], anchors, resized[i], dpi, nms_thresh=nms_thresh)
+        c = int(count[i])
+        assert c == len(b), (c, len(b))
+        torch.testing.assert_close(scores[i, :c].cpu(), s, rtol=0, atol=1e-6)
+        torch.testing.assert_close(boxes[i, :c].cpu(), b, rtol=1e-5, atol=2e-3)
 
 
 def test_detect_postprocess_no_candidates(cuda):
