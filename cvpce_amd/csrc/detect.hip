@@ -650,57 +650,70 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(NmsArgs a) {
     const int w = tid & 127, g = tid >> 7;                // word owned in the propagation step, group of 8 chunk rows
     // (the diagonal word of chunk b + 1 is fetched while chunk b is resolved and propagated: its L2 latency leaves the chain)
     unsigned long long diag_next = (wave == 0 && lane < T) ? M[(size_t)lane * a.words] : 0ull;
-    for (int b = 0; b < nw; ++b) {
-        if (wave == 0) {
-            const int row = b * 64 + lane;
-            const unsigned long long diag = diag_next;
-            {
-                int rn = row + 64;
-                rn = rn < T ? rn : T - 1;
-                const unsigned long long nx = M[(size_t)rn * a.words + (b + 1 < nw ? b + 1 : b)];
-                diag_next = (row + 64 < T) ? nx : 0ull;
-            }
-            const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
-            const int rows_here = (T - b * 64) < 64 ? (T - b * 64) : 64;
-            const unsigned long long valid = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
-            unsigned long long cur = rem[b];                // uniform
-            unsigned long long kept = 0ull;
-            unsigned long long avail = ~cur & valid;
-            while (avail) {
-                const int kk = __ffsll((long long)avail) - 1;
-                kept |= 1ull << kk;
-                const unsigned lo = __builtin_amdgcn_readlane(dlo, kk), hi = __builtin_amdgcn_readlane(dhi, kk);
-                cur |= ((unsigned long long)hi << 32) | lo;   // the diagonal word holds only bits above kk
-                avail = ~cur & valid & ~((2ull << kk) - 1ull);
-            }
-            const int nkept = s_nkept;
-            if ((kept >> lane) & 1ull) {
-                const int pos = nkept + __popcll(kept & ((1ull << lane) - 1ull));
-                if (pos < SORT_CAP) keep[pos] = row;
-            }
-            if (lane == 0) { s_kept = kept; s_nkept = nkept + __popcll(kept); }
-        }
-        __syncthreads();
-        const unsigned long long kept = s_kept;
-        if (s_nkept >= a.max_keep) break;
-        // propagate the kept rows of this chunk to the later words
-        if (w > b && w < nw) {
-            const unsigned sub = (unsigned)(kept >> (8 * g)) & 0xFFu;
-            if (sub) {
-                unsigned long long v[8];
+    // The rows a chunk may have to propagate -- thread (g, w): word w of its rows 8 g .. 8 g + 7 -- are fetched THREE chunks ahead
+    // into a register ring, whether the boxes turn out kept or not (40 KiB of L2 reads per chunk): fetched after the chunk was
+    // resolved, their ~1 us round trip was the length of a chunk step (105 us for the 79 chunks of dpi 1000).
+    unsigned long long pv[4][8];
+    auto fetch_rows = [&](int bb, unsigned long long (&dst)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int r = b * 64 + 8 * g + j;
-                    r = r < T ? r : T - 1;                  // (rows past the end are never kept: the value is masked below)
-                    v[j] = M[(size_t)r * a.words + w];
+        for (int j = 0; j < 8; ++j) {
+            int r = bb * 64 + 8 * g + j;
+            r = r < T ? r : T - 1;                          // (rows past the end are never kept: the value is masked out)
+            dst[j] = (bb < nw && w > bb && w < nw) ? M[(size_t)r * a.words + w] : 0ull;
+        }
+    };
+    fetch_rows(0, pv[0]);
+    fetch_rows(1, pv[1]);
+    fetch_rows(2, pv[2]);
+    bool full = false;
+    for (int b4 = 0; b4 < nw && !full; b4 += 4) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int b = b4 + s4;
+            if (b >= nw) break;
+            fetch_rows(b + 3, pv[(s4 + 3) & 3]);
+            if (wave == 0) {
+                const int row = b * 64 + lane;
+                const unsigned long long diag = diag_next;
+                {
+                    int rn = row + 64;
+                    rn = rn < T ? rn : T - 1;
+                    const unsigned long long nx = M[(size_t)rn * a.words + (b + 1 < nw ? b + 1 : b)];
+                    diag_next = (row + 64 < T) ? nx : 0ull;
                 }
+                const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
+                const int rows_here = (T - b * 64) < 64 ? (T - b * 64) : 64;
+                const unsigned long long valid = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+                unsigned long long cur = rem[b];                // uniform
+                unsigned long long kept = 0ull;
+                unsigned long long avail = ~cur & valid;
+                while (avail) {
+                    const int kk = __ffsll((long long)avail) - 1;
+                    kept |= 1ull << kk;
+                    const unsigned lo = __builtin_amdgcn_readlane(dlo, kk), hi = __builtin_amdgcn_readlane(dhi, kk);
+                    cur |= ((unsigned long long)hi << 32) | lo;   // the diagonal word holds only bits above kk
+                    avail = ~cur & valid & ~((2ull << kk) - 1ull);
+                }
+                const int nkept = s_nkept;
+                if ((kept >> lane) & 1ull) {
+                    const int pos = nkept + __popcll(kept & ((1ull << lane) - 1ull));
+                    if (pos < SORT_CAP) keep[pos] = row;
+                }
+                if (lane == 0) { s_kept = kept; s_nkept = nkept + __popcll(kept); }
+            }
+            __syncthreads();
+            const unsigned long long kept = s_kept;
+            if (s_nkept >= a.max_keep) { full = true; break; }
+            // propagate the kept rows of this chunk to the later words
+            if (w > b && w < nw) {
+                const unsigned sub = (unsigned)(kept >> (8 * g)) & 0xFFu;
                 unsigned long long acc = 0ull;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc |= ((sub >> j) & 1u) ? v[j] : 0ull;
+                for (int j = 0; j < 8; ++j) acc |= ((sub >> j) & 1u) ? pv[s4][j] : 0ull;
                 if (acc) atomicOr(&rem[w], acc);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     __syncthreads();
     const int nkept = s_nkept;

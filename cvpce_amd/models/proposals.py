@@ -392,6 +392,8 @@ class GLNEngine:
         x = ops.conv2d(x, self.g_subnet[0], act=1, in_up_shift=1)         # conv over up2(x), never materialised
         x = ops.conv2d(x, self.g_subnet[1], act=1)
         x = ops.conv2d(x, self.g_subnet[2], act=1)
+        if ops.can_fuse_gauss_tail(x, self.g_subnet[3], self.g_subnet[4]):
+            return ops.gauss_tail(x, self.g_subnet[3], self.g_subnet[4], 2 if self.tanh else 1)   # the two 1x1 layers in one launch
         x = ops.conv2d(x, self.g_subnet[3], act=1)
         return ops.conv2d(x, self.g_subnet[4], act=2 if self.tanh else 1, out_f32=True)  # (N,H/2,W/2,1) f32
 

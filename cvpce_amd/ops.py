@@ -492,6 +492,32 @@ def relu(x):
     return out
 
 
+USE_GAUSS_TAIL = _os.environ.get('CVPCE_GAUSS_TAIL', '1') != '0'   # A/B switch: the Gaussian subnet's two 1x1 layers in one launch
+
+
+def can_fuse_gauss_tail(x, c4, c5):
+    """cvpce_gauss_tail covers conv1x1(16 -> 16) + ReLU followed by conv1x1(16 -> 1) (proposals.py:96-107)."""
+    return (USE_GAUSS_TAIL and not FORCE_GENERIC_CONV and x.shape[-1] == 16 and c4.dtype == c5.dtype == x.dtype
+            and (c4.cin, c4.cin_pad, c4.cout, c4.kh, c4.kw, c4.stride, c4.pad) == (16, 16, 16, 1, 1, 1, 0)
+            and (c5.cin, c5.cin_pad, c5.cout, c5.kh, c5.kw, c5.stride, c5.pad) == (16, 16, 1, 1, 1, 1, 0))
+
+
+def gauss_tail(x, c4, c5, act):
+    """act(conv1x1_c5(relu(conv1x1_c4(x)))) -> (N,H,W,1) f32; x (N,H,W,16) bf16 | fp16; act 1 = ReLU, 2 = Tanh."""
+    _need_cuda(x)
+    assert can_fuse_gauss_tail(x, c4, c5) and x.is_contiguous() and act in (0, 1, 2)
+    out = torch.empty(x.shape[:3] + (1,), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.gauss_tail(x, c4.weight, c4.bias, c5.weight, c5.bias, out, c4.k_pad, int(act))
+    if prof is not None:
+        e1.record()
+        prof.records.append(('gauss_tail_kernel', 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * (16 * 16 + 16), e0, e1))
+    return out
+
+
 def global_max_into(x, out, out_off):
     """x NHWC bf16 -> out[:, out_off:out_off+C] (f32) = amax over H,W."""
     _need_cuda(x, out)

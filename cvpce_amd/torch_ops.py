@@ -132,6 +132,13 @@ def _relu(x, out):
     check(_by_dtype(x, 'cvpce_relu_bf16', 'cvpce_relu_f16', out)(_p(x), _p(out), x.numel(), _stream()), 'relu')
 
 
+@_op('gauss_tail(Tensor x, Tensor w2, Tensor? b2, Tensor w3, Tensor? b3, Tensor(a!) out, int k2_pad, int act) -> ()')
+def _gauss_tail(x, w2, b2, w3, b3, out, k2_pad, act):
+    assert x.shape[-1] == 16 and out.dtype == torch.float32 and out.numel() == x.numel() // 16
+    check(_by_dtype(x, 'cvpce_gauss_tail_bf16', 'cvpce_gauss_tail_f16', w2, w3)(_p(x), _p(w2), _p(b2), _p(w3), _p(b3), _p(out), x.numel() // 16,
+                                                                               k2_pad, act, _stream()), 'gauss_tail')
+
+
 @_op('global_max_nhwc(Tensor x, Tensor(a!) out, int out_off) -> ()')
 def _global_max_nhwc(x, out, out_off):
     n, h, w, c = x.shape

@@ -123,6 +123,11 @@ int cvpce_maxpool2d_nhwc_bf16(const void* in, void* out, int N, int H, int W, in
                               int Ho, int Wo, void* stream);
 /* F.relu on a bf16 buffer (LastLevelP6P7: p7(F.relu(p6))) */
 int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream);
+/* The last two layers of GaussianSubnet in one pass (cvpce/models/proposals.py:96-107: conv1x1 16 -> 16 + ReLU, conv1x1 16 -> 1 +
+ * ReLU (act 1) | Tanh (act 2)): x [npix][16] bf16, w2 [>= 16 rows][k2_pad] bf16 (k < 16 used), w3 [>= 1 row][..] bf16 (k < 16 of row 0),
+ * b2 [16] / b3 [1] f32 or NULL -> out [npix] f32.  The hidden layer is rounded to bf16 as the two-launch form stores it. */
+int cvpce_gauss_tail_bf16(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, float* out, long long npix,
+                          int k2_pad, int act, void* stream);
 /* x.amax(dim=(-2,-1)) -> out[n*out_stride + out_off + c]  (classification.py:46-49) */
 int cvpce_global_max_nhwc_bf16(const void* in, float* out, int N, int HW, int C, int out_stride, int out_off,
                                void* stream);
@@ -228,7 +233,9 @@ int cvpce_conv3x3_halo_list(const void* in, const void* wgt, const float* bias, 
  * entries; logits[l] -> f32 [N][gh*gw*A*K], regs[l] -> f32 [N][gh*gw*A][4] (NHWC conv outputs).
  * base_anchors f32 [L][A][4]; image_hw int [N][2] resized sizes; ratios f32 [N][2] (orig/resized h,w).
  * Outputs: boxes [N][dpi][4] (original pixels), scores [N][dpi], labels i64 [N][dpi], count [N],
- * conf_count [N] = #scores > conf_thresh. */
+ * conf_count [N] = #scores > conf_thresh.  The workspace (cvpce_detect_workspace_bytes: candidates, sorted candidates,
+ * the IoU bit matrix, N * L * 12 chunk runs of 8 KiB for the chunked top-k) is scratch: nothing is kept across calls.
+ * Ordering: by fp32 logit (a monotone refinement of the score order), then the lower index (csrc/detect.hip). */
 size_t cvpce_detect_workspace_bytes(int N, int L, int topk);
 int cvpce_detect_postprocess(const float* const* logits, const float* const* regs, const int* gh, const int* gw,
                              const int* stride_h, const int* stride_w, const float* base_anchors,
@@ -284,6 +291,8 @@ int cvpce_bottleneck_fused_f16(const void* x, const void* res, const void* w1, c
 int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad,
                              int Ho, int Wo, void* stream);
 int cvpce_relu_f16(const void* in, void* out, long long n, void* stream);
+int cvpce_gauss_tail_f16(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, float* out, long long npix,
+                         int k2_pad, int act, void* stream);
 int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,
                             const float* mean3, const float* std3, void* stream);
 int cvpce_gln_transform_batch_f16(const float* const* imgs, const int* H0, const int* W0, const int* h, const int* w, int n,

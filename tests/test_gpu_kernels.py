@@ -351,6 +351,35 @@ def test_detect_nms_second_phase(cuda, monkeypatch):
         torch.testing.assert_close(boxes[i, :c].cpu(), b, rtol=1e-5, atol=2e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [1, 2])
+def test_gauss_tail_parity(cuda, dtype, act):
+    """The Gaussian subnet's two 1x1 layers in one launch (proposals.py:96-107) against (a) the same two layers in fp32 on the same
+    16-bit operands with the hidden layer rounded where the two-launch form stores it, (b) the two conv launches themselves."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(17)
+    n, h, w = 2, 37, 41
+    x = torch.randn(n, 16, h, w, generator=g).relu()
+    w4, b4 = torch.randn(16, 16, 1, 1, generator=g) / 4, torch.randn(16, generator=g) * 0.1
+    w5, b5 = torch.randn(1, 16, 1, 1, generator=g) / 4, torch.randn(1, generator=g) * 0.1
+    c4 = ops.PackedConv(w4, b4, 1, 0, device=cuda, dtype=dtype)
+    c5 = ops.PackedConv(w5, b5, 1, 0, device=cuda, dtype=dtype)
+    rd = lambda t: t.to(dtype).to(torch.float32)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(cuda)
+    assert ops.can_fuse_gauss_tail(xin, c4, c5)
+    got = ops.gauss_tail(xin, c4, c5, act).cpu()
+    hid = rd(F.relu(F.conv2d(rd(x), rd(w4), b4)))
+    ref = F.conv2d(hid, rd(w5), b5)
+    ref = torch.tanh(ref) if act == 2 else F.relu(ref)
+    assert got.shape == (n, h, w, 1)
+    # (a hidden value that lands on a rounding boundary of the 16-bit type may round the other way under another summation order)
+    torch.testing.assert_close(got[..., 0], ref[:, 0], rtol=0, atol=2e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert (got[..., 0] - ref[:, 0]).abs().mean() < (2e-4 if dtype == torch.bfloat16 else 3e-5)
+    two = ops.conv2d(ops.conv2d(xin, c4, act=1), c5, act=act, out_f32=True).cpu()
+    torch.testing.assert_close(got, two, rtol=0, atol=2e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert (got - two).abs().mean() < (2e-4 if dtype == torch.bfloat16 else 3e-5)
+
+
 def test_detect_postprocess_no_candidates(cuda):
     from cvpce_amd import ops
     from cvpce_amd.models import proposals as P
