@@ -127,6 +127,7 @@ PROFILE = None   # set to a ConvProfile() to record
 
 
 CONV1X1_ANY_SHAPE = bool(int(_os.environ.get('CVPCE_CONV1X1_ANY', '0')))   # test switch: every eligible 1x1 conv through the pointwise kernel
+CONV1X1_STRIDE1 = _os.environ.get('CVPCE_CONV1X1_STRIDE1', '1') != '0'   # every stride-1 1x1 conv through the pointwise library entry (its streaming kernel, round 4; A/B switch)
 CONV1X1_MAX_CIN = int(_os.environ.get('CVPCE_CONV1X1_MAX_CIN', '256'))   # expansion convs up to this Cin (512 -- the 25 x 25 stage of ResNet-50 -- measured slower: 3.32 -> 3.36 ms detector only)
 ONE_OUTPUT_BLOCK = _os.environ.get('CVPCE_ONE_OUTPUT_BLOCK', '1') != '0'   # detect_postprocess outputs as views of one block (A/B switch)
 USE_CONV1X1 = True           # 1x1 convs with Cin, Cout % 64 == 0 through the LDS-free pointwise GEMM kernel (A/B switch)
@@ -169,7 +170,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         return out
     # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
     if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
-            and (CONV1X1_ANY_SHAPE or (cin <= CONV1X1_MAX_CIN and pc.cout >= 4 * cin)) and pc.cout % 64 == 0 and not out_f32 and not in_up_shift and not pool and act in (0, 1) and n * h * w * cin * 2 < 2 ** 32):
+            and (CONV1X1_ANY_SHAPE or (pc.stride == 1 and CONV1X1_STRIDE1) or (cin <= CONV1X1_MAX_CIN and pc.cout >= 4 * cin)) and pc.cout % 64 == 0 and not out_f32 and not in_up_shift and not pool and act in (0, 1) and n * h * w * cin * 2 < 2 ** 32):
         T.conv1x1_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.stride, ho, wo, pc.k_pad, pc.cout_pad, int(act), int(res_mode))
         if prof is not None:
             e1.record()
