@@ -14,7 +14,7 @@
 //     the 18 patch rows ONCE (ds_read_b128, immediate offsets, 4-deep register ring) and issues up to 6 MFMAs on it:
 //     108 fragment reads per chunk instead of 288 -- the reads were 21 % of conv4_2 (profiles/r01d_ablation_halo2.md).
 // Per chunk and wave: 6 steps x (18 ds_read_b128 + 96 MFMA 16x16x32 + 6 weight loads).
-// K order / weight layout: chunk-major [Cout_pad][K_pad] of include/cvpce_amd.h.  Fused bias / ReLU / MaxPool2d(2,2).
+// Weight layout: the fragment-major "halo weight layout" of include/cvpce_amd.h.  Fused bias / ReLU / MaxPool2d(2,2).
 #include "common.h"
 #include "../../include/cvpce_amd.h"
 
@@ -60,7 +60,7 @@ __device__ __forceinline__ int g2_col(int l16) { return l16 < 4 ? 2 * l16 : (l16
 
 struct Halo2Args {
     const bf16_t* in;    // [N][H][W][Cin]
-    const bf16_t* wgt;   // [Cout_pad][K_pad], chunk-major K
+    const bf16_t* wgt;   // fragment-major (include/cvpce_amd.h): [chunk][32-cout group][kw][K-half][kh][block][lane][8]
     const float* bias;
     const unsigned char* mask;   // optional [H][W]: output pixels with mask 0 are stored as zeros (atlas gaps); not with POOL
     bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]; null with gmax: nothing is stored (conv5_3)
@@ -70,6 +70,7 @@ struct Halo2Args {
     float* gmax;         // optional MAC descriptor [N][gmax_stride]: gmax[n][gmax_off + co] = max over the map (relu = 1)
     int gmax_stride, gmax_off;
     int N, H, W, Cin, Cout, K_pad, relu;
+    int cgroups;         // Cout_pad / 32: 32-cout groups per channel chunk of the fragment-major weights
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
     // LIST launches: the tiles to compute, ((ey_in << 16 | ex_in) << 32) | (n << 16) | (ty << 8) | tx, crop-major; *list_count
@@ -258,11 +259,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     // ---- weights: lane (m = l16, q = lq) loads 16 B = k 8q .. 8q+7 of row m of a 16-cout block.
     // MFMA row m = 4q' + j of block mt is cout 8q' + 4mt + j of the wave's 32: after both blocks accumulator lane group
     // q' holds 8 CONSECUTIVE couts (8q' .. 8q'+7) of its pixel -> one 16-byte store per pixel block ----
-    unsigned voff[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + 8 * (l16 >> 2) + 4 * mt + (l16 & 3)) * a.K_pad + lq * 8) * 2);
-    // scalar byte offset of (cout tile ct, channel chunk c): ct*TC rows down, c*576 k along
-    auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)(((unsigned)(ct * TC) * (unsigned)a.K_pad + (unsigned)c * 576u) * 2u)); };
+    // The weights arrive FRAGMENT-MAJOR (include/cvpce_amd.h, "halo weight layout"): the 16 bytes lane L needs for the fragment
+    // (chunk c, 32-cout group, kw, K-half, kh, block mt) sit at byte 16 L of that fragment's 1 KiB block, so a wave's weight load
+    // is ONE contiguous KiB.  From the row-major [Cout_pad][K_pad] layout the same load touched 16 rows with no two neighbouring
+    // lanes in one 64-byte block, and the texture addresser took one lane per clock for it (~61 clocks per load against 16:
+    // measured on the pointwise kernel, csrc/conv1x1.hip) -- the six loads per step of each of the eight waves kept it busy for
+    // about as long as the step's MFMAs run.
+    const unsigned voff1 = (unsigned)(lane * 16);
+    // scalar byte offset of the 36 blocks of (cout tile ct, channel chunk c) of this wave's 32 couts
+    auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)((unsigned)(c * a.cgroups + ct * (TC / 32) + wc) * 36864u)); };
 
     // ---- pixel fragments: lane (l16, lq) reads pixel (row p, column g2_col(l16) + kw), K-quarter lq of K-half hf:
     //      address = ((c3[kw] ^ (hf << 6) ^ ((p & 1) << 4)) + buffer) + (p * 18 + kw) * 128 ----
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     if constexpr (!(CVPCE_DBG & 8)) {                                                                          \
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
-                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + (kh_ * 3 + ((T) >> 1)) * 128 + ((T) & 1) * 64, 0); \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff1, (SBASE) + (((T) * 3 + kh_) * 2 + mt_) * 1024, 0); \
                 af[(T) % NA][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);                                       \
             }                                                                                                  \
     }
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
         constexpr int dbg8_ = CVPCE_DBG & 8;            // (the ablation build still loads the first step's weights)
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {
-                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], sb_cur + kh_ * 3 * 128, 0);
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff1, sb_cur + (kh_ * 2 + mt_) * 1024, 0);   // step 0
                 af[0][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);
                 if (dbg8_) af[1][kh_][mt_] = af[0][kh_][mt_];
             }
@@ -626,7 +631,7 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     Halo2Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = mask; a.out = (bf16_t*)out;
     a.gmax = gmax; a.gmax_stride = gmax_stride; a.gmax_off = gmax_off;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu; a.cgroups = Cout_pad / 32;
     a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T;
     a.tile_map = tile_map; a.tiles_per_image = tile_map ? n_map : a.tiles_x * a.tiles_y;
     a.ptiles = N * a.tiles_per_image;
@@ -714,7 +719,7 @@ static int halo_list_launch(const void* in, const void* wgt, const float* bias, 
     Halo2Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.mask = nullptr; a.out = (bf16_t*)out;
     a.gmax = mac; a.gmax_stride = mac_stride; a.gmax_off = mac_off;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu; a.cgroups = Cout_pad / 32;
     a.tiles_x = (W + G2_T - 1) / G2_T; a.tiles_y = (H + G2_T - 1) / G2_T;
     if (a.tiles_x > 255 || a.tiles_y > 255 || H > 65535 || W > 65535) return CVPCE_ERR_ARG;
     a.tile_map = nullptr; a.tiles_per_image = a.tiles_x * a.tiles_y;

@@ -38,10 +38,11 @@ __device__ __forceinline__ int g3_col(int l16) { return l16 < 4 ? 2 * l16 : (l16
 
 struct Halo3Args {
     const bf16_t* in;    // [N][H][W][Cin]
-    const bf16_t* wgt;   // [Cout_pad][K_pad], chunk-major K
+    const bf16_t* wgt;   // fragment-major (include/cvpce_amd.h)
     const float* bias;
     bf16_t* out;         // [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]
     int N, H, W, Cin, Cout, K_pad, relu;
+    int cgroups;         // Cout_pad / 32
     int tiles_x, tiles_y, ptiles, ctiles, ntiles;
     unsigned in_bytes, wgt_bytes;
     // LIST launches (see conv3x3_halo2.hip): the tiles to compute, *list_count entries; input pixels in the constant region of
@@ -177,12 +178,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     };
 
     // ---- weights: lane (m = l16, q = lq) loads 16 B = k 8q .. 8q+7 of row m of a 16-cout block ----
-    unsigned voff[2];
-#pragma unroll
     // MFMA row m = 4q + j of block mt is cout 8q + 4mt + j of the wave's 32: accumulator lane group q then holds 8
-    // CONSECUTIVE couts of its pixel -> one 16-byte store per pixel block
-    for (int mt = 0; mt < 2; ++mt) voff[mt] = (unsigned)(((wc * 32 + 8 * (l16 >> 2) + 4 * mt + (l16 & 3)) * a.K_pad + lq * 8) * 2);
-    auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)(((unsigned)(ct * TC) * (unsigned)a.K_pad + (unsigned)c * 576u) * 2u)); };
+    // CONSECUTIVE couts of its pixel -> one 16-byte store per pixel block.  The weights are FRAGMENT-MAJOR (see conv3x3_halo2.hip):
+    // the fragment of (chunk c, 32-cout group, kw, K-half, kh, block mt) is one contiguous KiB, lane L's 16 bytes at byte 16 L.
+    const unsigned voff1 = (unsigned)(lane * 16);
+    auto wbase = [&](int ct, int c) { return __builtin_amdgcn_readfirstlane((int)((unsigned)(c * a.cgroups + ct * (TC / 32) + wc) * 36864u)); };
 
     // ---- pixel fragments: lane (l16, lq) reads pixel (patch row p, column 16 wp + g3_col(l16) + kw), K-quarter lq:
     //      address = (c3[kw] + buffer) + (p * 34 + kw) * 64 ----
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     if constexpr (!(CVPCE_DBG & 8)) {                                                                          \
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
-                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff[mt_], (SBASE) + (kh_ * 3 + (T) % 3) * 128 + ((T) / 3) * 64, 0); \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff1, (SBASE) + (((((T) % 3) * 2 + (T) / 3) * 3 + kh_) * 2 + mt_) * 1024, 0); \
                 af[(T) & 1][kh_][mt_] = __builtin_bit_cast(bf16x8, v_);                                        \
             }                                                                                                  \
     }
@@ -449,7 +449,7 @@ static int halo3_dispatch(const void* in, const void* wgt, const float* bias, vo
     if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31)) return CVPCE_ERR_ARG;
     Halo3Args a;
     a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.out = (bf16_t*)out;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = relu; a.cgroups = Cout_pad / 32;
     a.tiles_x = (W + G3_TW - 1) / G3_TW; a.tiles_y = (H + G3_TH - 1) / G3_TH; a.ptiles = N * a.tiles_x * a.tiles_y;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);

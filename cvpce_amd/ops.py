@@ -81,6 +81,25 @@ class PackedConv:
         self.weight = to_storage(packed, dtype).to(device)
         self.bias = b.to(device) if b is not None else None
 
+    @property
+    def weight_halo(self):
+        """The weights in the fragment-major "halo weight layout" of include/cvpce_amd.h (3x3, Cin % 64 == 0), built on first use:
+        [64-channel chunk][32-cout group][kw][32-channel half][kh][16-cout block mt][lane = 16 q + m][8 channels], where lane (m, q)
+        of block mt holds cout 32 g + 8 (m >> 2) + 4 mt + (m & 3), channels 64 c + 32 half + 8 q .. + 7 of tap (kh, kw) -- one
+        contiguous KiB per MFMA weight fragment of the 3x3 halo kernels."""
+        if _os.environ.get('CVPCE_WEIGHT_ROWMAJOR') == '1':     # dev A/B against a library built before the layout change
+            return self.weight
+        w = self.__dict__.get('_weight_halo')
+        if w is None:
+            assert self.kh == 3 and self.kw == 3 and self.cin_pad % 64 == 0 and self.k_pad == 9 * self.cin_pad
+            nch = self.cin_pad // 64
+            # row-major packed: [cout_pad][chunk][kh][kw][64] -> (g, mq 4, mt 2, mj 4, c, kh, kw, half 2, q 4, e 8)
+            v = self.weight.view(torch.int16).reshape(self.cout_pad // 32, 4, 2, 4, nch, 3, 3, 2, 4, 8)
+            #                 -> (c, g, kw, half, kh, mt, q, mq, mj, e): lane = 16 q + 4 mq + mj
+            w = v.permute(4, 0, 6, 7, 5, 2, 8, 1, 3, 9).contiguous().view(self.weight.dtype).reshape(-1)
+            self._weight_halo = w
+        return w
+
     def out_hw(self, h, w, in_up_shift=0):
         h, w = h << in_up_shift, w << in_up_shift
         return ((h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1)
@@ -162,7 +181,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         e0.record()
     if halo:
         # (Cout <= 128 is forwarded to the wide-tile kernel, conv3x3_halo3.hip, inside the library)
-        T.conv3x3_halo(x, pc.weight, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool))
+        T.conv3x3_halo(x, pc.weight_halo, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool))
         if prof is not None:
             e1.record()
             prof.records.append(('conv3x3_halo3_kernel' if pc.cout <= 128 else 'conv3x3_halo2_kernel',
@@ -250,7 +269,7 @@ def conv2d_relu_mac(x, pc, mac, mac_off, store=True, pool=False):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    T.conv3x3_halo_mac(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(pool and store))
+    T.conv3x3_halo_mac(x, pc.weight_halo, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(pool and store))
     if prof is not None:
         e1.record()
         prof.records.append(('conv3x3_halo2_kernel', 2.0 * n * h * w * pc.cout * 9 * pc.cin, e0, e1))
@@ -333,7 +352,7 @@ def conv3x3_atlas(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None)
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    T.conv3x3_halo_masked(x, pc.weight, pc.bias, mask, tile_map, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
+    T.conv3x3_halo_masked(x, pc.weight_halo, pc.bias, mask, tile_map, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
     if prof is not None:
         e1.record()
         npix = float(mask.sum().item()) if mask_pixels is None else float(mask_pixels)
@@ -459,7 +478,7 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    T.conv3x3_halo_list(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), work, count)
+    T.conv3x3_halo_list(x, pc.weight_halo, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), work, count)
     if prof is not None:
         e1.record()
         wide = pc.cout <= 128
@@ -469,7 +488,7 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
                             + ((units, tile_flops / 16) if units is not None else (count, tile_flops)) + (f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else ''),))
     if strips is not None:
         assert pc.cout > 128
-        T.conv3x3_halo_strips(x, pc.weight, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
+        T.conv3x3_halo_strips(x, pc.weight_halo, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
         if prof is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
