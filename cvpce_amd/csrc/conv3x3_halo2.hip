@@ -749,3 +749,26 @@ extern "C" int cvpce_conv3x3_halo_strips(const void* in, const void* wgt, const 
                                          int fuse_pool2, const unsigned long long* strip_list, const int* count_dev, void* stream) {
     return halo_list_launch(in, wgt, bias, out, mac, mac_stride, mac_off, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, fuse_pool2, strip_list, count_dev, true, stream);
 }
+
+// [host] row-major chunk-major [Cout_pad][9 Cin] -> the fragment-major halo weight layout (include/cvpce_amd.h)
+extern "C" int cvpce_pack_halo_weights(const void* src_rowmajor, void* dst_halo, int Cout_pad, int Cin) {
+    if (!src_rowmajor || !dst_halo || Cout_pad <= 0 || Cout_pad % 32 != 0 || Cin <= 0 || Cin % 64 != 0) return CVPCE_ERR_ARG;
+    const unsigned short* src = (const unsigned short*)src_rowmajor;
+    unsigned short* dst = (unsigned short*)dst_halo;
+    const int nch = Cin / 64, groups = Cout_pad / 32;
+    const size_t K_pad = (size_t)9 * Cin;
+    size_t o = 0;
+    for (int c = 0; c < nch; ++c)
+        for (int g = 0; g < groups; ++g)
+            for (int kw = 0; kw < 3; ++kw)
+                for (int half = 0; half < 2; ++half)
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int mt = 0; mt < 2; ++mt)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int m = lane & 15, q = lane >> 4;
+                                const size_t row = (size_t)32 * g + 8 * (m >> 2) + 4 * mt + (m & 3);
+                                const size_t k = (size_t)c * 576 + (kh * 3 + kw) * 64 + half * 32 + q * 8;
+                                for (int e = 0; e < 8; ++e) dst[o++] = src[row * K_pad + k + e];
+                            }
+    return CVPCE_OK;
+}

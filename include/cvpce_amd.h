@@ -16,6 +16,11 @@
  *                                (chunk-major: the KH*KW taps of a 64-channel chunk are adjacent)
  *                 otherwise    : K index = (kh*KW + kw)*Cin + ci, K_pad % 32 == 0
  *                 (FrozenBN / BatchNorm-eval already folded in by the host)
+ *   halo weight layout (the `wgt` of every cvpce_conv3x3_halo* entry point; 3x3, Cin % 64 == 0): the same Cout_pad x K_pad
+ *                 values FRAGMENT-MAJOR, one contiguous KiB per MFMA weight fragment --
+ *                 [ci/64][cout/32][kw][(ci%64)/32][kh][mt][lane][8] with lane = 16 q + m, m = 0..15, q = 0..3:
+ *                 lane (m, q) of block mt holds cout 32 (cout/32) + 8 (m >> 2) + 4 mt + (m & 3), channels
+ *                 64 (ci/64) + 32 ((ci%64)/32) + 8 q .. + 7 of tap (kh, kw).  cvpce_pack_halo_weights converts.
  */
 #ifndef CVPCE_AMD_H
 #define CVPCE_AMD_H
@@ -70,8 +75,14 @@ int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, co
 int cvpce_gln_stem_fused(const void* in_nhwc8, const void* w_frag, const float* bias, void* out, int N, int H, int W,
                          void* stream);
 
+/* [host] The row-major conv weights of a 3x3 layer with Cin % 64 == 0 ([Cout_pad][K_pad = 9 Cin] 16-bit values, chunk-major K)
+ * into the fragment-major halo weight layout (same size; `src` and `dst` are HOST buffers and must not overlap). */
+int cvpce_pack_halo_weights(const void* src_rowmajor, void* dst_halo, int Cout_pad, int Cin);
+
 /* 3x3 / stride 1 / pad 1 convolution with Cin % 64 == 0 and the input halo patch resident in LDS (VGG16 conv2_2 ..
- * conv5_3, RetinaNet head / FPN 3x3s): same operands, weight layout and numerics as cvpce_conv2d_nhwc_bf16; any H, W
+ * conv5_3, RetinaNet head / FPN 3x3s): same operands and numerics as cvpce_conv2d_nhwc_bf16 with the weights in the HALO
+ * WEIGHT LAYOUT (a wave's weight fragment is one contiguous KiB: row-major, its 16 row pieces cost the texture addresser
+ * one lane per clock); any H, W
  * (ragged 16x16 tiles are masked; H, W even when pooling), Cout % 8 == 0;
  * relu = 0/1; fuse_pool2 = 1 stores MaxPool2d(2,2) of the result ([N][H/2][W/2][Cout]). */
 int cvpce_conv3x3_halo(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,

@@ -40,7 +40,7 @@ def test_torch_ops_registered_for_the_gpu_only():
     """north_star: "exposed to Python through PyTorch-ROCm custom ops".  One dispatcher entry per C-ABI compute entry point,
     CUDA (= HIP) key only: a CPU tensor is refused by the dispatcher itself -- no CPU kernel exists to fall back to."""
     from cvpce_amd import torch_ops
-    declared = {s for s in header_symbols() if not s.endswith('_bytes') and s != 'cvpce_set_persistent_workgroups'}
+    declared = {s for s in header_symbols() if not s.endswith('_bytes') and s not in ('cvpce_set_persistent_workgroups', 'cvpce_pack_halo_weights')}   # (host-only helpers)
     # the fp16 twins of the detector's kernels (round 3) are reached through the SAME ops: the op picks the entry point by the
     # activations' dtype (torch_ops._by_dtype) -- every twin must have its bf16 original declared too
     twins = {s for s in declared if s.endswith('_f16')}
@@ -202,3 +202,22 @@ def test_gallery_reader_pool_keeps_order():
         items = list(c._gallery_items(Slow()))
         assert [a for _, a in items] == [f'a{i}' for i in range(37)]
         assert all(float(t[0, 0, 0]) == i for i, (t, _) in enumerate(items))
+
+
+def test_halo_weight_layout_host_packer_matches_the_python_one():
+    """The fragment-major weight layout of the 3x3 halo kernels has two writers -- `PackedConv.weight_halo` (torch permute, what
+    the product path uses) and the C ABI's host helper `cvpce_pack_halo_weights` (for a non-Python caller): same bytes, and
+    every value of the row-major tensor appears exactly once."""
+    import ctypes
+    from cvpce_amd import ops
+    from cvpce_amd._lib import lib
+    g = torch.Generator().manual_seed(5)
+    for cout, cin in ((96, 64), (256, 128), (512, 192)):
+        pc = ops.PackedConv(torch.randn(cout, cin, 3, 3, generator=g), None, 1, 1, device='cpu')
+        src = pc.weight.contiguous()
+        dst = torch.empty_like(src).reshape(-1)
+        rc = lib.cvpce_pack_halo_weights(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), pc.cout_pad, pc.cin_pad)
+        assert rc == 0
+        assert torch.equal(dst.view(torch.int16), pc.weight_halo.view(torch.int16))
+        assert torch.equal(dst.view(torch.int16).sort().values, src.view(torch.int16).reshape(-1).sort().values)
+    assert lib.cvpce_pack_halo_weights(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), 256, 48) == 1
