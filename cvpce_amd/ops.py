@@ -78,27 +78,30 @@ class PackedConv:
             wp = wp.reshape(self.cout_pad, kh, kw, self.cin_pad // 64, 64).permute(0, 3, 1, 2, 4)
         packed = torch.zeros(self.cout_pad, self.k_pad, dtype=torch.float32)
         packed[:, :k] = wp.reshape(self.cout_pad, k)
-        self.weight = to_storage(packed, dtype).to(device)
+        w16 = to_storage(packed, dtype)
+        self.weight = w16.to(device)
         self.bias = b.to(device) if b is not None else None
+        # the 3x3 halo kernels (csrc/conv3x3_halo2.hip, conv3x3_halo3.hip) read the same values fragment-major
+        self._weight_halo = (self._to_halo_layout(w16, self.cout_pad, self.cin_pad).to(device)
+                             if (kh, kw) == (3, 3) and self.cin_pad % 64 == 0 else None)
 
     @property
     def weight_halo(self):
-        """The weights in the fragment-major "halo weight layout" of include/cvpce_amd.h (3x3, Cin % 64 == 0), built on first use:
-        [64-channel chunk][32-cout group][kw][32-channel half][kh][16-cout block mt][lane = 16 q + m][8 channels], where lane (m, q)
-        of block mt holds cout 32 g + 8 (m >> 2) + 4 mt + (m & 3), channels 64 c + 32 half + 8 q .. + 7 of tap (kh, kw) -- one
-        contiguous KiB per MFMA weight fragment of the 3x3 halo kernels."""
+        """The weights in the fragment-major "halo weight layout" of include/cvpce_amd.h (3x3, Cin % 64 == 0; built with the layer)."""
         if _os.environ.get('CVPCE_WEIGHT_ROWMAJOR') == '1':     # dev A/B against a library built before the layout change
             return self.weight
-        w = self.__dict__.get('_weight_halo')
-        if w is None:
-            assert self.kh == 3 and self.kw == 3 and self.cin_pad % 64 == 0 and self.k_pad == 9 * self.cin_pad
-            nch = self.cin_pad // 64
-            # row-major packed: [cout_pad][chunk][kh][kw][64] -> (g, mq 4, mt 2, mj 4, c, kh, kw, half 2, q 4, e 8)
-            v = self.weight.view(torch.int16).reshape(self.cout_pad // 32, 4, 2, 4, nch, 3, 3, 2, 4, 8)
-            #                 -> (c, g, kw, half, kh, mt, q, mq, mj, e): lane = 16 q + 4 mq + mj
-            w = v.permute(4, 0, 6, 7, 5, 2, 8, 1, 3, 9).contiguous().view(self.weight.dtype).reshape(-1)
-            self._weight_halo = w
-        return w
+        return self._weight_halo
+
+    @staticmethod
+    def _to_halo_layout(weight, cout_pad, cin_pad):
+        """[64-channel chunk][32-cout group][kw][32-channel half][kh][16-cout block mt][lane = 16 q + m][8 channels], where lane (m, q)
+        of block mt holds cout 32 g + 8 (m >> 2) + 4 mt + (m & 3), channels 64 c + 32 half + 8 q .. + 7 of tap (kh, kw) -- one
+        contiguous KiB per MFMA weight fragment of the 3x3 halo kernels."""
+        nch = cin_pad // 64
+        # row-major packed: [cout_pad][chunk][kh][kw][64] -> (g, mq 4, mt 2, mj 4, c, kh, kw, half 2, q 4, e 8)
+        v = weight.view(torch.int16).reshape(cout_pad // 32, 4, 2, 4, nch, 3, 3, 2, 4, 8)
+        #                 -> (c, g, kw, half, kh, mt, q, mq, mj, e): lane = 16 q + 4 mq + mj
+        return v.permute(4, 0, 6, 7, 5, 2, 8, 1, 3, 9).contiguous().view(weight.dtype).reshape(-1)
 
     def out_hw(self, h, w, in_up_shift=0):
         h, w = h << in_up_shift, w << in_up_shift
