@@ -372,22 +372,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
                     }
                 }
             } else {
-                const int ox = tx * G3_TW + 16 * wp + col;
+                // A lane holds 8 consecutive couts (16 bytes) of ITS pixel, and neighbouring lanes are neighbouring pixels, Cout * 2 bytes
+                // apart: stored as they are, the 64 pieces of a store instruction share no 64-byte block and the texture addresser
+                // takes them one lane per clock (see conv3x3_halo2.hip on the weight loads).  The 16 x 4 (pixel, cout group) pieces
+                // are transposed across the wave first (4 ds_bpermute per row): lane 4 p + q then holds cout group q of pixel p,
+                // and four neighbouring lanes write one contiguous 64-byte run.
+                const int tp = lane >> 2, tq = lane & 3;                // after the exchange: pixel column index tp, cout group tq
+                const int src4 = (16 * tq + tp) * 4;                    // byte address of the source lane (lq = tq, lp = tp)
+                const int ox = tx * G3_TW + 16 * wp + g3_col(tp);
+                const int co = ct * TC + wc * 32 + 8 * tq;
 #pragma unroll
                 for (int nt = 0; nt < NB; ++nt) {
                     const int oy = ty * G3_TH + nt;
                     const size_t opix = (size_t)(n * a.H + oy) * a.W + ox;
                     const bool store_lane = oy < a.H && ox < a.W && (!LIST || nt < rows_t);     // ragged right / bottom tiles; (LIST) computed rows only
-                    const int co = ct * TC + wc * 32 + 8 * lq;        // this lane's 8 consecutive couts
                     f32x4 r0 = acc[0][nt], r1 = acc[1][nt];
                     if (a.relu) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { r0[j] = relu_bits(r0[j]); r1[j] = relu_bits(r1[j]); }
                     }
-                    if (store_lane && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
-                        const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(r0)), h2 = __builtin_bit_cast(uint2, E::pack4(r1));
-                        *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = u32x4{l2.x, l2.y, h2.x, h2.y};
-                    }
+                    const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(r0)), h2 = __builtin_bit_cast(uint2, E::pack4(r1));
+                    u32x4 v;
+                    v[0] = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)l2.x);
+                    v[1] = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)l2.y);
+                    v[2] = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)h2.x);
+                    v[3] = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)h2.y);
+                    if (store_lane && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345))
+                        *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = v;
                 }
             }
 #pragma unroll
