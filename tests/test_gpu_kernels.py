@@ -680,6 +680,9 @@ C1X1_CASES = [  # n, cin, h, w, cout, stride, res ('', 'same', 'up'), act
     (1, 1024, 13, 17, 256, 1, 'up', 0),      # FPN lateral + nearest-upsampled top-down
     (2, 512, 7, 9, 2048, 1, 'same', 1),      # layer4 expand, ragged last pixel tile
     (1, 2048, 5, 5, 512, 1, '', 1),          # deep K
+    (1, 128, 5, 7, 192, 1, 'same', 1),       # 3 cout tiles (not a power of two: the LDS-staged weights form), 35 pixels in all
+    (2, 128, 61, 67, 512, 1, 'same', 1),     # K = 128: weights in registers, ragged last pixel tile, more tiles than persistent waves
+    (1, 64, 30, 31, 128, 1, 'up', 1),        # K = 64 (one stage), upsampled residual
 ]
 
 
