@@ -16,6 +16,7 @@
 // Per chunk and wave: 6 steps x (18 ds_read_b128 + 96 MFMA 16x16x32 + 6 weight loads).
 // Weight layout: the fragment-major "halo weight layout" of include/cvpce_amd.h.  Fused bias / ReLU / MaxPool2d(2,2).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/cvpce_amd.h"
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -94,10 +95,14 @@ extern "C" int cvpce_debug_halo2_clock(unsigned long long* host_out) {
 // tile's MFMAs against a full tile's weight stream, which is what bounds them (profiles/r04_rejected_experiments.md); here patch
 // rows 6s .. 6s + 5 of the 18-row patch belong to strip s, accumulator rows 4s .. 4s + 3 are its outputs, and the three share
 // every weight fragment: 72 MFMAs per step and wave for three tiles' worth of useful rows.
-template <typename E, bool POOL, bool GMAX, bool LIST, bool STRIP = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
+// NW (waves = 32-cout groups per workgroup): 8 -> a 256-cout tile; 4 -> a 128-cout tile for launches with too few pixel tiles to fill
+// the chip (the detector's 50 x 50 and 25 x 25 maps: 128 / 32 tiles of 16 x 16 pixels for 256 compute units): twice the workgroups,
+// each with half the weight stream and the same patch.
+template <typename E, bool POOL, bool GMAX, bool LIST, bool STRIP = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv3x3_halo2_kernel(Halo2Args a) {
     static_assert(!STRIP || LIST, "strips come from a work list");
-    constexpr int TC = 256, NB = 16, NS = STRIP ? 3 : 1;
+    static_assert(NW == 8 || NW == 4, "cout waves");   // (two waves on a 64-cout tile for the 25 x 25 maps: measured, no further gain)
+    constexpr int TC = 32 * NW, NB = 16, NS = STRIP ? 3 : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ap = smem;                 // [3][328][64] bf16
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     unsigned long long* llist = reinterpret_cast<unsigned long long*>(smem + G2_LLIST_OFF);
     if constexpr (LIST) {
         const int staged = my_tiles * NS < G2_MAX_SEQ ? my_tiles * NS : G2_MAX_SEQ;
-        for (int idx = tid; idx < staged; idx += 512) {
+        for (int idx = tid; idx < staged; idx += 64 * NW) {
             const int k = l_first * NS + idx;                                    // (STRIP: past the end of the list the last entry is repeated --
             llist[idx] = a.list[k < l_entries ? k : l_entries - 1];              //  a strip computed twice stores the same values twice)
         }
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     unsigned* ltile = reinterpret_cast<unsigned*>(smem + G2_LTILE_OFF);
     unsigned short* lrow = reinterpret_cast<unsigned short*>(smem + G2_LROW_OFF);
     if (a.mask) {
-        for (int idx = tid; idx < my_tiles * 16; idx += 512) {
+        for (int idx = tid; idx < my_tiles * 16; idx += 64 * NW) {
             const int sq = idx >> 4, y = idx & 15;
             const int r = ((lbid + sq * (int)gridDim.x) / a.ctiles) % a.tiles_per_image;
             int ty, tx;
@@ -205,17 +210,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo2_kernel(Halo2Args a) {
     };
 
     // ---- patch DMA: piece j fills patch rows 8j .. 8j+7 (row = lane>>3, phys chunk = lane&7); pieces dealt
-    //      round-robin to the 8 waves (wave w: pieces w, w+8, ...; 6 for w = 0, else 5) ----
-    const int npp = (wc == 0) ? 6 : 5;
+    //      round-robin to the NW waves (wave w: pieces w, w + NW, ...; 41 pieces: 6 for w = 0, else 5 with eight waves) ----
+    constexpr int NPP = (41 + NW - 1) / NW;
+    const int npp = (41 - wc + NW - 1) / NW;
     auto issue_patch = [&](const int* n, const int* ty, const int* tx, int c, int buf, const int* ext) {
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the volatile
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NPP; ++i) {
             if (i < npp) {
-                const int j = wc + 8 * i;
+                const int j = wc + NW * i;
                 const int pp = j * 8 + (ln >> 3);
                 const int py = pp / G2_P, px = pp - py * G2_P;
                 const int lchunk = (ln & 7) ^ g2_swz(py, px);
@@ -598,6 +604,18 @@ template <typename E, bool POOL, bool GMAX, bool LIST = false, bool STRIP = fals
 static int launch_halo2(Halo2Args a, hipStream_t stream) {
     a.ctiles = (a.Cout + 255) / 256;
     a.ntiles = a.ptiles * a.ctiles;
+    if constexpr (!POOL && !GMAX && !LIST) {
+        // few pixel tiles (the detector's small maps): 128-cout tiles on twice as many workgroups
+        static const bool narrow_ok = !(getenv("CVPCE_HALO_NARROW") && getenv("CVPCE_HALO_NARROW")[0] == '0');   // dev A/B switch
+        if (narrow_ok && !a.mask && a.Cout % 128 == 0 && 2 * a.ntiles <= g_cvpce_persistent_wgs) {
+            a.ctiles = a.Cout / 128;
+            a.ntiles = a.ptiles * a.ctiles;
+            if (!cvpce_smem_attr_done<conv3x3_halo2_kernel<E, false, false, false, false, 4>>((const void*)conv3x3_halo2_kernel<E, false, false, false, false, 4>, 3 * G2_A_BYTES))
+                return CVPCE_ERR_LAUNCH;
+            hipLaunchKernelGGL((conv3x3_halo2_kernel<E, false, false, false, false, 4>), dim3(a.ntiles), dim3(256), 3 * G2_A_BYTES, stream, a);
+            return cvpce_check_launch();
+        }
+    }
     const int smem = a.mask ? G2_SMEM_MASKED : (LIST ? G2_SMEM_LIST : 3 * G2_A_BYTES);
     if (!cvpce_smem_attr_done<conv3x3_halo2_kernel<E, POOL, GMAX, LIST, STRIP>>((const void*)conv3x3_halo2_kernel<E, POOL, GMAX, LIST, STRIP>, G2_SMEM_MASKED))
         return CVPCE_ERR_LAUNCH;
