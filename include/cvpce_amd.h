@@ -49,10 +49,12 @@ int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, c
                            int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
                            int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
 
-/* 1x1 convolution (nn.Conv2d(k=1, stride s, pad 0) of the ResNet-50 bottlenecks / downsample paths and the FPN lateral
- * convs) as an LDS-free pointwise GEMM: Cin % 64 == 0 (= K_pad), Cout % 64 == 0; same operands, weight layout, residual
- * modes (0 none, 1 same-size add, 2 nearest-upsampled add from [N][Hr][Wr][Cout]) and numerics as
- * cvpce_conv2d_nhwc_bf16; relu = 0/1; out: [N][Ho][Wo][Cout] bf16 with Ho = (H-1)/stride + 1. */
+/* 1x1 convolution (nn.Conv2d(k=1, stride s, pad 0) of the ResNet-50 bottlenecks / downsample paths, the FPN lateral convs and the
+ * Gaussian layer's lateral, proposals.py:68) as a pointwise GEMM: Cin % 64 == 0 (= K_pad), Cout % 64 == 0; same operands, weight
+ * layout, residual modes (0 none, 1 same-size add, 2 nearest-upsampled add from [N][Hr][Wr][Cout]) and numerics as
+ * cvpce_conv2d_nhwc_bf16; relu = 0/1; out: [N][Ho][Wo][Cout] bf16 with Ho = (H-1)/stride + 1.  stride 1: streaming kernels (both
+ * operands through per-wave LDS by coalesced LDS-DMA, no barrier, persistent waves; Cin <= 256 and a power-of-two Cout / 64: the
+ * wave's weights stay in registers); other strides: operands loaded in fragment layout. */
 int cvpce_conv1x1_nhwc_bf16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H,
                             int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad, int relu,
                             int res_mode, int Hr, int Wr, void* stream);
