@@ -190,6 +190,14 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
             prof.records.append(('conv3x3_halo3_kernel' if pc.cout <= 128 else 'conv3x3_halo2_kernel',
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
         return out
+    # thin 3x3 layers (the Gaussian subnet's 32 -> 32 / 32 -> 16 over the 400 x 400 map): weights in registers, input rows streamed through LDS
+    if (USE_THIN_3X3 and not FORCE_GENERIC_CONV and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and cin == 32 and pc.cin == 32 and pc.cout in (16, 32)
+            and pc.k_pad == 288 and not out_f32 and residual is None and not in_up_shift and not pool and act in (0, 1) and n * h * w * 64 < 2 ** 32 - 65536):
+        T.conv3x3_thin(x, pc.weight, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
+        if prof is not None:
+            e1.record()
+            prof.records.append(('thin3x3_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+        return out
     # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
     if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
             and (CONV1X1_ANY_SHAPE or (pc.stride == 1 and CONV1X1_STRIDE1) or (cin <= CONV1X1_MAX_CIN and pc.cout >= 4 * cin)) and pc.cout % 64 == 0 and not out_f32 and not in_up_shift and not pool and act in (0, 1) and n * h * w * cin * 2 < 2 ** 32):
@@ -207,6 +215,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     return out
 
 
+USE_THIN_3X3 = _os.environ.get('CVPCE_THIN_3X3', '1') != '0'   # A/B switch: the thin 3x3 layers through csrc/thin3x3.hip
 USE_FUSED_BOTTLENECK = _os.environ.get('CVPCE_FUSED_BOTTLENECK', '1') != '0'   # A/B switch: stride-1 ResNet bottlenecks (P <= 256) in one launch (csrc/bneck.hip)
 
 
