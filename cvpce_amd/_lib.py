@@ -42,7 +42,7 @@ SIGNATURES = {
     'cvpce_maxpool2d_nhwc_bf16': (c_int, [_vp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_relu_bf16': (c_int, [_vp, _vp, c_longlong, _vp]),
     'cvpce_pack_halo_weights': (c_int, [_vp, _vp, c_int, c_int]),
-    'cvpce_conv3x3_thin_bf16': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 8 + [_vp]),
+    'cvpce_conv3x3_thin_bf16': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_gauss_tail_bf16': (c_int, [_vp, _vp, _fp, _vp, _fp, _fp, c_longlong, c_int, c_int, _vp]),
     'cvpce_global_max_nhwc_bf16': (c_int, [_vp, _fp, c_int, c_int, c_int, c_int, c_int, _vp]),
     'cvpce_l2_normalize_f32': (c_int, [_fp, _fp, _vp, c_int, c_int, c_float, _vp]),

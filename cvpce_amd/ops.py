@@ -190,10 +190,13 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
             prof.records.append(('conv3x3_halo3_kernel' if pc.cout <= 128 else 'conv3x3_halo2_kernel',
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
         return out
-    # thin 3x3 layers (the Gaussian subnet's 32 -> 32 / 32 -> 16 over the 400 x 400 map): weights in registers, input rows streamed through LDS
-    if (USE_THIN_3X3 and not FORCE_GENERIC_CONV and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and cin == 32 and pc.cin == 32 and pc.cout in (16, 32)
-            and pc.k_pad == 288 and not out_f32 and residual is None and not in_up_shift and not pool and act in (0, 1) and n * h * w * 64 < 2 ** 32 - 65536):
-        T.conv3x3_thin(x, pc.weight, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act))
+    # thin 3x3 layers (the Gaussian subnet's 64 -> 32 over an upsampled input, 32 -> 32, 32 -> 16, all on the 400 x 400 map): weights in
+    # registers, input rows streamed through LDS (csrc/thin3x3.hip)
+    thin_shape = ((cin, pc.cin, pc.k_pad) == (32, 32, 288) and pc.cout in (16, 32) and not in_up_shift) or \
+                 ((cin, pc.cin, pc.k_pad) == (64, 64, 576) and pc.cout == 32 and in_up_shift == 1)
+    if (USE_THIN_3X3 and not FORCE_GENERIC_CONV and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and thin_shape
+            and not out_f32 and residual is None and not pool and act in (0, 1) and n * ho * wo * 64 < 2 ** 32 - 65536):
+        T.conv3x3_thin(x, pc.weight, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act), int(in_up_shift))
         if prof is not None:
             e1.record()
             prof.records.append(('thin3x3_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))

@@ -132,11 +132,12 @@ def _relu(x, out):
     check(_by_dtype(x, 'cvpce_relu_bf16', 'cvpce_relu_f16', out)(_p(x), _p(out), x.numel(), _stream()), 'relu')
 
 
-@_op('conv3x3_thin(Tensor x, Tensor weight, Tensor? bias, Tensor(a!) out, int cout, int k_pad, int cout_pad, int relu) -> ()')
-def _conv3x3_thin(x, weight, bias, out, cout, k_pad, cout_pad, relu):
+@_op('conv3x3_thin(Tensor x, Tensor weight, Tensor? bias, Tensor(a!) out, int cout, int k_pad, int cout_pad, int relu, int in_up_shift) -> ()')
+def _conv3x3_thin(x, weight, bias, out, cout, k_pad, cout_pad, relu, in_up_shift):
     n, h, w, cin = x.shape
     fn = _by_dtype(x, 'cvpce_conv3x3_thin_bf16', 'cvpce_conv3x3_thin_f16', weight, out)
-    check(fn(_p(x), _p(weight), _p(bias), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, _stream()), 'cvpce_conv3x3_thin')
+    check(fn(_p(x), _p(weight), _p(bias), _p(out), n, h << in_up_shift, w << in_up_shift, cin, cout, k_pad, cout_pad, relu, in_up_shift, _stream()),
+          'cvpce_conv3x3_thin')
 
 
 @_op('gauss_tail(Tensor x, Tensor w2, Tensor? b2, Tensor w3, Tensor? b3, Tensor(a!) out, int k2_pad, int act) -> ()')

@@ -77,11 +77,14 @@ int cvpce_vgg_stem_fused(const void* in_nhwc, int in_cstride, const void* w1, co
 int cvpce_gln_stem_fused(const void* in_nhwc8, const void* w_frag, const float* bias, void* out, int N, int H, int W,
                          void* stream);
 
-/* 3x3 / stride 1 / pad 1 convolution of a THIN layer: Cin = 32 (K_pad = 288, row-major weights as for cvpce_conv2d_nhwc_bf16), Cout = 16 | 32
- * -- GaussianSubnet's 3x3 32 -> 32 and 32 -> 16 over the 400 x 400 map (cvpce/models/proposals.py:81-107).  A wave keeps the layer's
- * weights in registers and walks down a 16-pixel column strip with a ring of input rows in LDS; relu = 0/1; out bf16 [N][H][W][Cout]. */
+/* 3x3 / stride 1 / pad 1 convolution of a THIN layer (GaussianSubnet, cvpce/models/proposals.py:81-107; row-major weights as for
+ * cvpce_conv2d_nhwc_bf16): in_up_shift 0: Cin = 32 (K_pad 288), Cout = 16 | 32 -- the 3x3 32 -> 32 and 32 -> 16 over the 400 x 400 map;
+ * in_up_shift 1: Cin = 64 (K_pad 576), Cout = 32, `in` is [N][H/2][W/2][64] and is read through its nearest-2x upsample
+ * (GaussianLayer's `self.up`, proposals.py:79, never materialised) -- the subnet's first layer.  H, W: the OUTPUT size.  A wave
+ * keeps the layer's weights in registers and walks down a 16-pixel column strip with a ring of input rows in LDS; relu = 0/1; out bf16
+ * [N][H][W][Cout]. */
 int cvpce_conv3x3_thin_bf16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin, int Cout,
-                            int K_pad, int Cout_pad, int relu, void* stream);
+                            int K_pad, int Cout_pad, int relu, int in_up_shift, void* stream);
 
 /* [host] The row-major conv weights of a 3x3 layer with Cin % 64 == 0 ([Cout_pad][K_pad = 9 Cin] 16-bit values, chunk-major K)
  * into the fragment-major halo weight layout (same size; `src` and `dst` are HOST buffers and must not overlap). */
@@ -311,7 +314,7 @@ int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int
                              int Ho, int Wo, void* stream);
 int cvpce_relu_f16(const void* in, void* out, long long n, void* stream);
 int cvpce_conv3x3_thin_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin, int Cout,
-                           int K_pad, int Cout_pad, int relu, void* stream);
+                           int K_pad, int Cout_pad, int relu, int in_up_shift, void* stream);
 int cvpce_gauss_tail_f16(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, float* out, long long npix,
                          int k2_pad, int act, void* stream);
 int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,

@@ -381,28 +381,30 @@ def test_gauss_tail_parity(cuda, dtype, act):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('n,h,w,cout,act', [(2, 37, 45, 32, 1), (1, 103, 16, 16, 1), (3, 7, 70, 32, 0), (1, 51, 33, 16, 0)])
-def test_conv3x3_thin_parity(cuda, dtype, n, h, w, cout, act):
+@pytest.mark.parametrize('n,h,w,cout,act,up', [(2, 37, 45, 32, 1, 0), (1, 103, 16, 16, 1, 0), (3, 7, 70, 32, 0, 0), (1, 51, 33, 16, 0, 0),
+                                                  (2, 19, 23, 32, 1, 1), (1, 52, 8, 32, 1, 1), (1, 3, 40, 32, 0, 1)])
+def test_conv3x3_thin_parity(cuda, dtype, n, h, w, cout, act, up):
     """The thin 3x3 kernel (Cin 32 -> Cout 16 | 32: the Gaussian subnet's layers, proposals.py:81-107) against F.conv2d on the same
     16-bit operands and against the implicit-GEMM kernel: ragged strips (W % 16 != 0), more / fewer rows than a 50-row task, the
     image border rows and columns (zero padding through the buffer range check)."""
     from cvpce_amd import ops
     g = torch.Generator().manual_seed(100 * h + w + cout)
     rd = lambda t: t.to(dtype).to(torch.float32)
-    x = rd(torch.randn(n, 32, h, w, generator=g))
-    wgt = torch.randn(cout, 32, 3, 3, generator=g) / math.sqrt(288)
+    cin = 64 if up else 32          # up: (h, w) is the STORED size, the conv runs over its nearest-2x upsample (proposals.py:79)
+    x = rd(torch.randn(n, cin, h, w, generator=g))
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
     bias = torch.randn(cout, generator=g) * 0.1
     pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda, dtype=dtype)
-    ref = F.conv2d(x, rd(wgt), bias, padding=1)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode='nearest') if up else x, rd(wgt), bias, padding=1)
     if act:
         ref = F.relu(ref)
     xin = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(cuda)
     ops.PROFILE = ops.ConvProfile()
     try:
-        y = ops.conv2d(xin, pc, act=act)
+        y = ops.conv2d(xin, pc, act=act, in_up_shift=up)
         assert ops.PROFILE.records[-1][0] == 'thin3x3_kernel'
         ops.USE_THIN_3X3 = False
-        y2 = ops.conv2d(xin, pc, act=act)
+        y2 = ops.conv2d(xin, pc, act=act, in_up_shift=up)
         assert ops.PROFILE.records[-1][0] != 'thin3x3_kernel'
     finally:
         ops.USE_THIN_3X3 = True
