@@ -13,7 +13,10 @@ Workloads (`--workload`):
 Extra legs of the pipeline workload (all outside the timed region of `value`):
   roofline      per-kernel HIP-event timing of the conv kernels + per-stage times
   value_with_h2d  the same K steps with the images uploaded from pinned host memory on a copy stream, batch i+1 during batch i
-  parity        tests/accuracy.py on a bounded sample: HIP pipeline (bf16 defaults) vs the fp32 oracle (AP / AR300 / top-1)
+  value_lists_off / value_planted_boxes / value_fitted_scenes_p200   the same whole pipeline with the constant-padding work lists off,
+                on 8 x 200 PLANTED proposals of 60-250 px (seed 7) and on fitted-scene proposals padded to P = 200: how
+                much of `value` is a property of the random-weight detector's box shapes
+  parity        tests/accuracy.py on a bounded sample: HIP pipeline (product defaults) vs the fp32 oracle (AP / AR300 / top-1)
   cpu_baseline  the oracle timed on this box's host cores
   --verify      per-image SHA-256 of (boxes, scores, matched indices) gathered to rank 0: identical for 1/2/4/8-GPU runs
 """
@@ -49,8 +52,9 @@ def parse():
     ap.add_argument('--gallery', type=int, default=3200)
     ap.add_argument('--detections-per-img', type=int, default=None, help='default 200 (pipeline, cli/eval.py:50) / 1000 (detector)')
     ap.add_argument('--match-dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--detector-precision', default='bf16', choices=['bf16', 'fp16'],
-                    help="storage type of the detector's weights / activations: bf16 (default, what BASELINE's configs name) or the fp16 accuracy mode")
+    ap.add_argument('--detector-precision', default='fp16', choices=['bf16', 'fp16'],
+                    help="storage type of the detector's weights / activations: fp16 (the product default: the mode that meets north_star's 0.1 pt "
+                         "tolerance, same MFMA rate) or bf16 (opt-in; the embedder and the matcher compute in bf16 in both)")
     ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; value = the median window')
     ap.add_argument('--no-workloads', action='store_true', help='skip the configs[1] / configs[3] figures appended to the pipeline line')
     ap.add_argument('--verify', action='store_true', help='gather per-image result digests to rank 0 (8e: identical across world sizes)')
@@ -61,6 +65,7 @@ def parse():
     ap.add_argument('--no-parity', action='store_true', help='skip the bounded HIP-vs-oracle accuracy sample')
     ap.add_argument('--no-h2d', action='store_true', help='skip the H2D-inclusive leg')
     ap.add_argument('--no-precision-leg', action='store_true', help='skip the extra timed window in the other detector precision')
+    ap.add_argument('--no-coheadlines', action='store_true', help='skip the lists-off / planted-box whole-pipeline windows (value_lists_off, value_planted_boxes)')
     return ap.parse_args()
 
 
@@ -227,33 +232,67 @@ def conv_roofline(summ, stages=None):
     # HBM bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the figure measured
     # by the same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (two passes, gfx950 FETCH x2
     # correction) and committed under profiles/; null if no profile covers the kernel
-    traffic = None
-    traffic_note = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
-        v = prof.get(name)            # keyed by the names ops.ConvProfile uses (tools/summarise_profiles.py)
-        # the file is stamped with the sha256 of the library it was collected on: figures of another build are not reported
-        from cvpce_amd import _lib
-        sha = hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
-        if prof.get('_library_sha256') != sha:
-            traffic_note = 'profiles/hbm_traffic.json was collected on another build of libcvpce_hip.so: not reported'
-        elif v is not None:
-            traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4)
-    except Exception:
-        traffic = None
+    prof, traffic_note = _pmc_traffic()     # (stamped with the sha256 of the library it was collected on: another build's figures are not reported)
+    v = prof.get(name) if prof else None    # keyed by the names ops.ConvProfile uses (tools/summarise_profiles.py)
+    traffic = round((v['read_bytes_per_launch'] + v['write_bytes_per_launch']) / 1e9, 4) if v is not None else None
     out = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'GB/launch (rocprofv3 PMC, profiles/)',
            'kernel': name, 'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
            'share_of_conv_time': round(dom['ms'] / sum(v['ms'] for v in summ.values()), 4),
            'flops': 'EXECUTED (tiles on the work lists; the skipped constant-padding tiles are not counted)',
-           'algorithmic_tflops': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
+           # the layers' ALGORITHMIC FLOPs over the same time: a throughput in units of whole crops, NOT a hardware rate (it can exceed
+           # the MFMA peak where padding tiles are skipped) -- never compare it with `peak`
+           'images_equivalent_tflops': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
     if traffic_note:
         out['traffic_note'] = traffic_note
     if stages is not None:
         out['stages'] = stages
     out['all_conv_kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                    'tflops': round(v.get('flops_executed', v['flops']) / (v['ms'] * 1e-3) / 1e12, 2),
-                                   'algorithmic_tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+                                   'frac_of_mfma_peak': round(v.get('flops_executed', v['flops']) / (v['ms'] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                                   'images_equivalent_tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+    return out
+
+
+def _pmc_traffic():
+    """profiles/hbm_traffic.json (per-launch HBM bytes by kernel, rocprofv3 PMC passes summarised by tools/summarise_profiles.py), or
+    (None, why) when it was collected on another build of the library than the one loaded now."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+        from cvpce_amd import _lib
+        sha = hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+        if prof.get('_library_sha256') != sha:
+            return None, 'profiles/hbm_traffic.json was collected on another build of libcvpce_hip.so: not reported'
+        return prof, None
+    except Exception as e:                                   # noqa: BLE001 (a missing / unreadable file is "no figure", never a failure)
+        return None, f'profiles/hbm_traffic.json unreadable: {type(e).__name__}'
+
+
+def hbm_stages(summ_bytes, steps, copy_gbs=None):
+    """`roofline.hbm_stages`: the HBM-bound stages of a step (input transform, RoI crop, the detector's 1x1 convs, the Gaussian
+    subnet's thin 3x3 convs and its 1x1 tail) against the HBM roofline: ALGORITHMIC bytes per step (every input / output tensor of a
+    launch once, weights included; the crop: every source pixel of every box once + the crops written), HIP-event time, GB/s, the
+    fraction of the nominal 8 TB/s -- and, where profiles/hbm_traffic.json covers the kernel on THIS build, the measured PMC bytes
+    (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and their ratio to the algorithmic bytes (> 1.3 is flagged: wasted re-reads)."""
+    pmc, why = _pmc_traffic()
+    out = {}
+    for name, d in summ_bytes.items():
+        ms, gb = d['ms'] / steps, d['bytes'] / steps / 1e9
+        e = {'launches_per_step': round(d['launches'] / steps, 1), 'algorithmic_gb_per_step': round(gb, 4), 'ms_per_step': round(ms, 4),
+             'gbs': round(gb / ms * 1e3, 1) if ms > 0 else None, 'frac_of_hbm_peak': round(gb / ms * 1e3 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+        v = pmc.get(name) if pmc else None
+        if v is not None and v.get('launches'):
+            per_launch = v['read_bytes_per_launch'] + v['write_bytes_per_launch']
+            e['pmc_gb_per_launch'] = round(per_launch / 1e9, 4)
+            e['algorithmic_gb_per_launch'] = round(d['bytes'] / d['launches'] / 1e9, 4)
+            e['pmc_over_algorithmic'] = round(per_launch / (d['bytes'] / d['launches']), 3)
+            e['pmc_gbs'] = round(per_launch / 1e9 / (d['ms'] / d['launches']) * 1e3, 1)
+            e['flag_wasted_traffic'] = bool(e['pmc_over_algorithmic'] > 1.3)
+        out[name] = e
+    if why:
+        out['_pmc_note'] = why
+    out['_note'] = ('bound = hbm for every stage here; peak = 8000 GB/s nominal (MI355X_MICROARCH.md); measured device copy rate: '
+                    'measured_peaks.device_copy_gbs')
     return out
 
 
@@ -279,6 +318,11 @@ def gather_digests(local, world):
     return merged
 
 
+def _sync(dev):
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+
+
 def timed_windows(step, steps, windows, dev, collective=True):
     """`windows` back-to-back timed regions of EXACTLY `steps` calls of `step()`, each bracketed by barrier +
     torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  -> (median seconds, [seconds per window]).
@@ -287,14 +331,14 @@ def timed_windows(step, steps, windows, dev, collective=True):
     from cvpce_amd import dist as cdist
     secs = []
     for _ in range(max(1, windows)):
-        torch.cuda.synchronize()
+        _sync(dev)
         if collective:
             cdist.barrier()
-            torch.cuda.synchronize()
+            _sync(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        _sync(dev)
         if collective:
             cdist.barrier()
         dt = time.perf_counter() - t0
@@ -344,10 +388,83 @@ def run_h2d_leg(pipe, host_images, dev, steps, warmup):
     return time.perf_counter() - t0
 
 
-def run_pipeline(args, rank, local_rank, world, dev):
-    from cvpce_amd import dist as cdist, ops, production, synthetic
-    ipg = args.images_per_gpu or 8
-    dpi = args.detections_per_img or 200
+def planted_proposals(n_images, dpi, image_size, dev, seed=7):
+    """PLANTED proposals -- exactly `dpi` boxes per image, both sides uniform in 60-250 px and independent, uniformly
+    placed on the image_size^2 canvas, seed 7.  -> (boxes (N,dpi,4) f32, counts (N,) int32) on `dev` (BatchedPipeline.run(proposals=...))."""
+    g = torch.Generator().manual_seed(seed)
+    wh = 60 + 190 * torch.rand(n_images * dpi, 2, generator=g)
+    xy = torch.rand(n_images * dpi, 2, generator=g) * (float(image_size) - wh)
+    boxes = torch.cat((xy, xy + wh), dim=1).view(n_images, dpi, 4)
+    return boxes.to(dev), torch.full((n_images,), dpi, dtype=torch.int32, device=dev)
+
+
+def crop_shape_stats(boxes):
+    b = boxes.reshape(-1, 4).to(torch.long).float().cpu()
+    bw, bh = (b[:, 2] - b[:, 0]).clamp(min=1), (b[:, 3] - b[:, 1]).clamp(min=1)
+    return {'short_over_long_mean': round(float((torch.minimum(bw, bh) / torch.maximum(bw, bh)).mean()), 4),
+            'wide_fraction': round(float((bw > bh).float().mean()), 4)}
+
+
+def executed_fraction(run_once):
+    """One profiled pass of `run_once()` -> (executed / algorithmic conv FLOPs, {kernel: executed TFLOP/s})."""
+    from cvpce_amd import ops
+    ops.PROFILE = ops.ConvProfile()
+    try:
+        run_once()
+        summ = ops.PROFILE.summary()
+    finally:
+        ops.PROFILE = None
+    alg = sum(v['flops'] for v in summ.values())
+    exe = sum(v.get('flops_executed', v['flops']) for v in summ.values())
+    return round(exe / max(alg, 1.0), 4), summ
+
+
+def coheadline_legs(pipe, images, ipg, dpi, image_size, steps, dev):
+    """The WHOLE pipeline (detect + crop + embed + match, same images, same gallery, same kernels) timed twice more on rank 0, one window
+    of `steps` steps each: (a) with the constant-padding work lists OFF -- every tile of every crop computed, the figure that does not
+    depend on the boxes' shapes; (b) on PLANTED proposals, exactly `dpi` per image, 60-250 px with independent sides --
+    a realistic spread of aspect ratios instead of the random-weight detector's uniform 2.6 : 1 boxes.  Each with the fraction of
+    the algorithmic conv FLOPs its launches executed.  (datautils.py:232-239 is the padding rule the lists exploit.)"""
+    from cvpce_amd.models import classification as C
+    out = {}
+    # (a) lists off
+    was = C.SKIP_PADDING
+    C.SKIP_PADDING = False
+    try:
+        for _ in range(2):
+            pipe.run(images)
+        t, _ = timed_windows(lambda: pipe.run(images), steps, 1, dev, collective=False)
+        frac, summ_off = executed_fraction(lambda: pipe.run(images))
+    finally:
+        C.SKIP_PADDING = was
+    out['lists_off'] = {'images_per_s': round(ipg * steps / t, 3), 'ms_per_step': round(t / steps * 1e3, 3), 'executed_over_algorithmic_conv_flops': frac,
+                        'what': 'CVPCE_SKIP_PADDING=0: every tile of every crop is computed'}
+    dom = summ_off.get('conv3x3_halo2_kernel')
+    if dom:
+        ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        out['lists_off']['dominant_kernel'] = {'kernel': 'conv3x3_halo2_kernel', 'achieved_tflops': round(ach, 2), 'frac': round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                                               'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2), 'launches': dom['launches']}
+        out['lists_off']['all_conv_kernels'] = {k: {'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
+                                                     'frac_of_mfma_peak': round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+                                                for k, v in summ_off.items() if k in ('conv3x3_halo2_kernel', 'conv3x3_halo3_kernel', 'vgg_stem2_kernel')}
+    # (b) planted proposals through the whole pipeline
+    prop = planted_proposals(len(images), dpi, image_size, dev)
+    for _ in range(2):
+        pipe.run(images, proposals=prop)
+    t, _ = timed_windows(lambda: pipe.run(images, proposals=prop), steps, 1, dev, collective=False)
+    frac, _ = executed_fraction(lambda: pipe.run(images, proposals=prop))
+    out['planted_boxes'] = dict({'images_per_s': round(ipg * steps / t, 3), 'ms_per_step': round(t / steps * 1e3, 3), 'proposals_per_image': dpi,
+                                 'executed_over_algorithmic_conv_flops': frac,
+                                 'what': f'the detector runs, then exactly {dpi} planted boxes per image (60-250 px uniform, independent sides, seed 7) replace '
+                                         'its boxes for crop + embed + match'}, **crop_shape_stats(prop[0]))
+    return out
+
+
+def build_pipeline(args, rank, world, dev, ipg, dpi):
+    """Models, the sharded gallery build with its ONE all_gather, this rank's images -> dict(pipe, clf, enc, images, host_images, ids,
+    gallery, t_gallery, det_sd, enc_sd).  (tests/test_dist_cpu.py swaps this for a CPU stand-in through CVPCE_BENCH_STUB to drive
+    main() under 8 gloo ranks; nothing else of bench.py is replaced there.)"""
+    from cvpce_amd import dist as cdist, production, synthetic
     det = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=args.detector_precision)
     enc = synthetic.synthetic_macvgg(seed=1)
     det_sd = {k: v.clone() for k, v in det.state_dict().items()} if rank == 0 else None
@@ -376,6 +493,36 @@ def run_pipeline(args, rank, local_rank, world, dev):
     host_images = [synthetic.shelf_image(g, args.image_size, args.image_size) for g in ids]
     images = [h.to(dev) for h in host_images]
     torch.cuda.synchronize()
+    return {'pipe': pipe, 'clf': clf, 'enc': enc, 'images': images, 'host_images': host_images, 'ids': ids, 'gallery': gallery,
+            't_gallery': t_gallery, 'det_sd': det_sd, 'enc_sd': enc_sd}
+
+
+def stub_factory():
+    """CVPCE_BENCH_STUB='module:function' (tests only): a CPU stand-in for `build_pipeline` with the same signature and keys, so that
+    main() -- argument parsing, sharding, the gallery all_gather, the timed windows' barriers and MAX reduction, the --verify gather,
+    the rank-0-only tail -- can run under N gloo ranks on a box without a GPU.  The stand-in's dict may carry 'rank0_leg', a callable
+    standing for the long rank-0-only side legs.  Every GPU-only leg is off in that mode."""
+    spec = os.environ.get('CVPCE_BENCH_STUB')
+    if not spec:
+        return None
+    import importlib
+    mod, fn = spec.split(':')
+    return getattr(importlib.import_module(mod), fn)
+
+
+def run_pipeline(args, rank, local_rank, world, dev):
+    from cvpce_amd import dist as cdist
+    ipg = args.images_per_gpu or 8
+    dpi = args.detections_per_img or 200
+    stub = stub_factory()
+    if stub is not None:
+        args.no_h2d = args.no_roofline = args.no_workloads = args.no_peaks = args.no_parity = args.no_cpu_baseline = True
+        args.no_precision_leg = args.no_coheadlines = True
+    else:
+        from cvpce_amd import ops, production, synthetic
+    built = (stub or build_pipeline)(args, rank, world, dev, ipg, dpi)
+    pipe, images, host_images, ids = built['pipe'], built['images'], built['host_images'], built['ids']
+    clf, enc, gallery, t_gallery, det_sd, enc_sd = (built.get(k) for k in ('clf', 'enc', 'gallery', 't_gallery', 'det_sd', 'enc_sd'))
 
     outs = [None]
 
@@ -384,25 +531,13 @@ def run_pipeline(args, rank, local_rank, world, dev):
 
     for _ in range(args.warmup):
         step()
+    coll_before = dict(cdist.STATS)
     elapsed, window_secs = timed_windows(step, args.steps, args.windows, dev)
+    coll_after = dict(cdist.STATS)
     out = outs[0]
     proposals = float(sum(out['counts_host'])) / max(1, len(images))
 
-    # the same step with the detector in its OTHER storage mode (fp16 = the accuracy mode that meets the parity tolerance,
-    # DESIGN.md 2a; bf16 = the type BASELINE's configs name): one more timed window on rank 0
-    by_precision = None
-    if rank == 0 and not args.no_precision_leg:
-        other = 'fp16' if args.detector_precision == 'bf16' else 'bf16'
-        det2 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=other).to(dev)
-        pipe2 = production.BatchedPipeline(det2, clf, 0.5)
-        for _ in range(max(2, args.warmup)):
-            pipe2.run(images)
-        t2, _ = timed_windows(lambda: pipe2.run(images), args.steps, 1, dev, collective=False)
-        by_precision = {args.detector_precision: round(ipg * args.steps / elapsed, 3), other: round(ipg * args.steps / t2, 3),
-                        'note': 'images/s per GPU with the detector storing bf16 / fp16; the second figure is one extra timed window of '
-                                '--steps steps on rank 0 right after the headline windows, same box, same images'}
-        del pipe2, det2
-
+    # ---- the legs EVERY rank takes part in come first (their barriers must not wait for rank 0's side legs) -----------------------
     verify = None
     if args.verify:
         merged = gather_digests([(g, image_digest(out, i)) for i, g in enumerate(ids)], world)
@@ -419,6 +554,37 @@ def run_pipeline(args, rank, local_rank, world, dev):
                'upload_mb_per_step': round(sum(h.numel() * 4 for h in host_images) / 1e6, 1),
                'how': 'pinned host staging, uploads of batch i+1 on a copy stream during batch i (double-buffered)'}
         del pinned
+    collectives = cdist.collective_stats()
+    if collectives is not None:
+        # what the timed windows themselves issued: per window two barriers + one MAX reduction of the window's seconds, at the window
+        # boundaries -- nothing between the steps (no steady-state collectives)
+        collectives['in_timed_windows'] = {k: coll_after[k] - coll_before[k] for k in ('all_gather', 'all_reduce', 'barrier')}
+        collectives['data_path_collectives_per_step'] = 0
+        collectives['gallery_all_gather_mb'] = round(collectives['all_gather_bytes_received'] / 1e6, 2)
+
+    # ---- rank-0-only side legs (no collectives below this line: the other ranks are on their way out) -----------------------------
+    # the same step with the detector in its OTHER storage mode (fp16 = the product default, the mode that meets the parity tolerance,
+    # DESIGN.md 2a; bf16 = the opt-in): one more timed window
+    by_precision = None
+    if rank == 0 and not args.no_precision_leg:
+        other = 'fp16' if args.detector_precision == 'bf16' else 'bf16'
+        det2 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=other).to(dev)
+        pipe2 = production.BatchedPipeline(det2, clf, 0.5)
+        for _ in range(max(2, args.warmup)):
+            pipe2.run(images)
+        t2, _ = timed_windows(lambda: pipe2.run(images), args.steps, 1, dev, collective=False)
+        by_precision = {args.detector_precision: round(ipg * args.steps / elapsed, 3), other: round(ipg * args.steps / t2, 3),
+                        'note': 'images/s per GPU with the detector storing fp16 (default) / bf16; the second figure is one extra timed window of '
+                                '--steps steps on rank 0 right after the headline windows, same box, same images'}
+        del pipe2, det2
+
+    if rank == 0 and built.get('rank0_leg') is not None:
+        built['rank0_leg']()
+    cohead = None
+    if rank == 0 and not args.no_coheadlines:
+        cohead = coheadline_legs(pipe, images, ipg, dpi, args.image_size, args.steps, dev)
+        cohead['headline'] = dict({'images_per_s': round(ipg * args.steps / elapsed, 3), 'proposals_per_image': proposals}, **crop_shape_stats(
+            torch.cat([out['boxes'][i, :c] for i, c in enumerate(out['counts_host'])])))
 
     roofline = None
     if not args.no_roofline and rank == 0:
@@ -426,6 +592,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
         for _ in range(args.steps):
             pipe.run(images)
         summ = ops.PROFILE.summary()
+        summ_bytes = ops.PROFILE.summary_bytes()
         ops.PROFILE = None
         alg_conv = sum(v['flops'] for v in summ.values()) / args.steps / 1e9
         exe_conv = sum(v.get('flops_executed', v['flops']) for v in summ.values()) / args.steps / 1e9
@@ -441,17 +608,19 @@ def run_pipeline(args, rank, local_rank, world, dev):
             stages[nm] = {'ms_per_step': round(ms, 3), 'algorithmic_gflop': round(gf, 1), 'executed_gflop': round(ex, 1),
                           'tflops': round(ex / ms, 1) if ms > 0 else None,
                           'frac_of_mfma_peak': round(ex / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4) if ms > 0 else None,
-                          'algorithmic_tflops': round(gf / ms, 1) if ms > 0 else None}
+                          'images_equivalent_tflops': round(gf / ms, 1) if ms > 0 else None}
         roofline = conv_roofline(summ, stages)
+        roofline['hbm_stages'] = hbm_stages(summ_bytes, args.steps)
         alg_step = sum(stage_gflop(nm, len(images), proposals, args.gallery) for nm in ('detect', 'embed', 'match'))
         roofline['gflop_per_step'] = {
             'algorithmic': round(alg_step, 1), 'executed': round(alg_step - (alg_conv - exe_conv), 1),
             'note': 'algorithmic = SURVEY.md 8(d) (298.4 GFLOP detector + 40.09 GFLOP per crop + matcher); executed = without the embedder tiles '
                     'that lie in the crops\' constant 0.5-padding (datautils.py:232-239) and are skipped, results bit-identical; `tflops` / `frac` '
-                    'figures of this object are EXECUTED work over time, `algorithmic_tflops` the algorithmic work over the same time'}
+                    'figures of this object are EXECUTED work over time; `images_equivalent_tflops` = the algorithmic work over the same time '
+                    '(a throughput in whole-crop units, not a hardware rate)'}
         roofline['end_to_end'] = {'executed_tflops': round((alg_step - (alg_conv - exe_conv)) / (elapsed / args.steps * 1e3), 1),
                                   'frac_of_mfma_peak': round((alg_step - (alg_conv - exe_conv)) / (elapsed / args.steps * 1e3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                                  'algorithmic_tflops': round(alg_step / (elapsed / args.steps * 1e3), 1)}
+                                  'images_equivalent_tflops': round(alg_step / (elapsed / args.steps * 1e3), 1)}
         # shape of the crops of this step (the padding a crop carries is 1 - short / long side of its box)
         c0 = out['counts_host']
         bx = torch.cat([out['boxes'][i, :c0[i]] for i in range(len(images))]).to(torch.long).float()
@@ -537,10 +706,23 @@ def run_pipeline(args, rank, local_rank, world, dev):
                    'match_dtype': args.match_dtype, 'detector_precision': args.detector_precision,
                    'weights': 'seeded random init, cls head calibrated (cvpce_amd/synthetic.py)',
                    'parallelism': f'dp{world} (images sharded by global index, gallery embedded sharded + 1 all_gather, no steady-state collectives)',
-                   'gallery_build_s': round(t_gallery, 3), 'collectives': cdist.backend_name()},
+                   'gallery_build_s': round(t_gallery, 3), 'collectives': collectives},
     }
     if h2d is not None:
         line.update(h2d)
+    if cohead is not None:
+        # co-headlines (same metric, same whole pipeline, same gallery): `value` above is measured on the random-weight detector's boxes, whose
+        # uniform 2.6 : 1 shape lets the embedder skip ~45 % of its FLOPs as constant padding; these three do not depend on that
+        line['value_lists_off'] = cohead['lists_off']['images_per_s']
+        line['value_planted_boxes'] = cohead['planted_boxes']['images_per_s']
+        fsp = (workloads or {}).get('pipeline_fitted_scenes', {}).get('padded_to_p')
+        if fsp:
+            line['value_fitted_scenes_p200'] = fsp['images_per_s']
+            cohead['fitted_scenes_p200'] = fsp
+        line['co_headlines'] = cohead
+        if roofline is not None and 'dominant_kernel' in cohead['lists_off']:
+            # the dominant kernel with every tile computed (executed = algorithmic FLOPs): the fraction that no box shape flatters
+            roofline['lists_off'] = cohead['lists_off']['dominant_kernel']
     for key, val in (('value_by_detector_precision', by_precision), ('roofline', roofline), ('measured_peaks', peaks), ('parity', parity),
                      ('cpu_baseline', cpu), ('workloads', workloads), ('verify', verify)):
         if val is not None:
@@ -573,7 +755,22 @@ def fitted_scenes_pipeline(dev, clf, ipg, dpi, image_size, steps, precision):
     bx = torch.cat([out['boxes'][i, :counts[i]] for i in range(len(images))]).to(torch.long).float()
     bw, bh = (bx[:, 2] - bx[:, 0]).clamp(min=1), (bx[:, 3] - bx[:, 1]).clamp(min=1)
     emb = {k: v for k, v in summ.items() if k in ('vgg_stem2_kernel', 'conv3x3_halo3_kernel')}
-    return {'images': ipg, 'images_per_s': round(ipg * steps / t, 2), 'ms_per_step': round(t / steps * 1e3, 3), 'detector_precision': precision,
+    # the same scenes padded to EXACTLY P = dpi proposals per image: the detector's confident boxes, cycled (box j of the padding = confident
+    # box j mod c) -- the near-square shape distribution of real products at the headline's proposal count
+    pb = out['boxes'].clone()
+    for i, c in enumerate(counts):
+        if 0 < c < dpi:
+            pb[i, c:] = pb[i, :c].repeat((dpi + c - 1) // c, 1)[:dpi - c]
+    prop = (pb, torch.full((len(images),), dpi, dtype=torch.int32, device=dev))
+    for _ in range(2):
+        pipe.run(images, proposals=prop)
+    tp, _ = timed_windows(lambda: pipe.run(images, proposals=prop), steps, 1, dev, collective=False)
+    fracp, _ = executed_fraction(lambda: pipe.run(images, proposals=prop))
+    p200 = dict({'images_per_s': round(ipg * steps / tp, 3), 'ms_per_step': round(tp / steps * 1e3, 3), 'proposals_per_image': dpi,
+                 'executed_over_algorithmic_conv_flops': fracp,
+                 'what': 'fitted-scene proposals (near-square product boxes) padded to exactly P boxes per image by cycling the confident boxes'},
+                **crop_shape_stats(pb))
+    return {'padded_to_p': p200, 'images': ipg, 'images_per_s': round(ipg * steps / t, 2), 'ms_per_step': round(t / steps * 1e3, 3), 'detector_precision': precision,
             'confident_boxes_per_image': round(sum(counts) / len(counts), 1), 'products_per_image': round(sum(len(sc[1]) for sc in scenes) / len(scenes), 1),
             'short_over_long_mean': round(float((torch.minimum(bw, bh) / torch.maximum(bw, bh)).mean()), 4), 'wide_fraction': round(float((bw > bh).float().mean()), 4),
             'embed_stem_and_conv2_executed_over_algorithmic': round(sum(v['flops_executed'] for v in emb.values()) / max(1.0, sum(v['flops'] for v in emb.values())), 4),
@@ -766,8 +963,11 @@ def main():
         args.gpus = world
     if world > 1:
         torch.set_num_threads(host_threads_for(world, os.cpu_count() or 1))
-    dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
-    torch.cuda.set_device(dev)
+    if stub_factory() is not None:
+        dev = torch.device('cpu')                 # CVPCE_BENCH_STUB (tests/test_dist_cpu.py): the rehearsal of main() on a box without a GPU
+    else:
+        dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
+        torch.cuda.set_device(dev)
     line = {'pipeline': run_pipeline, 'detector': run_detector, 'match-stress': run_match_stress}[args.workload](args, rank, local_rank, world, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)

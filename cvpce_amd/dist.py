@@ -12,6 +12,18 @@ import torch
 import torch.distributed as dist
 
 
+# every collective this process issues, by kind: bench.py prints it (`config.collectives`) so that a run on N GPUs shows that the
+# process group really had N ranks, that the gallery all_gather ran once, and that no collective sits inside the timed steps
+STATS = {'all_gather': 0, 'all_gather_bytes_sent': 0, 'all_gather_bytes_received': 0, 'all_reduce': 0, 'barrier': 0}
+
+
+def collective_stats():
+    """-> dict | None (no process group): backend, the world size THE PROCESS GROUP reports, and the counts / bytes above."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dict(STATS, backend=dist.get_backend(), world_size=dist.get_world_size())
+
+
 def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
@@ -60,6 +72,9 @@ def all_gather_rows(local, total_rows, rank, world):
     pad[:local.shape[0]] = local.to(stage)
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
+    STATS['all_gather'] += 1
+    STATS['all_gather_bytes_sent'] += pad.numel() * pad.element_size()
+    STATS['all_gather_bytes_received'] += pad.numel() * pad.element_size() * world
     return torch.cat([o[:e - s] for o, (s, e) in zip(out, sizes)]).to(dev)
 
 
@@ -75,11 +90,13 @@ def max_over_ranks(value, device):
         return value
     t = torch.tensor([value], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    STATS['all_reduce'] += 1
     return float(t.item())
 
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
+        STATS['barrier'] += 1
         if dist.get_backend() == 'nccl':
             dist.barrier(device_ids=[torch.cuda.current_device()])     # RCCL: the barrier's all_reduce runs on THIS rank's GPU
         else:

@@ -240,9 +240,9 @@ def resized_hw(h, w):
 class GLNEngine:
     """Weights packed for the HIP kernels (bf16 [Cout][K], FrozenBN/BN folded) + the launch schedule."""
 
-    def __init__(self, model, device, precision='bf16'):
-        """precision: storage type of the detector's weights and inter-layer activations -- 'bf16' (default; what BASELINE's
-        configs name) or 'fp16' (the accuracy mode: 10 instead of 7 mantissa bits at the same MFMA rate; head logits, box
+    def __init__(self, model, device, precision=ops.DEFAULT_DETECTOR_PRECISION):
+        """precision: storage type of the detector's weights and inter-layer activations -- 'fp16' (default: 10 mantissa bits, the
+        mode that meets the 0.1 pt tolerance) or 'bf16' (opt-in: 7 mantissa bits at the same MFMA rate; head logits, box
         regressions and gaussians are fp32 in both)."""
         if precision not in ops.STORAGE_TYPES:
             raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
@@ -626,7 +626,7 @@ class GaussianLayerNetwork(nn.Module):
     def __init__(self, resnet, num_classes, gaussian_loss_params={}, tanh=False, detections_per_img=1000, precision=None, **kwargs):
         super().__init__()
         if precision is None:       # (the CLI commands keep the reference's options: the environment selects the mode there)
-            precision = os.environ.get('CVPCE_DETECTOR_PRECISION', 'bf16')
+            precision = os.environ.get('CVPCE_DETECTOR_PRECISION', ops.DEFAULT_DETECTOR_PRECISION)
         if precision not in ops.STORAGE_TYPES:
             raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
         self.precision = precision
@@ -645,7 +645,7 @@ class GaussianLayerNetwork(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def set_precision(self, precision):
-        """'bf16' (default) | 'fp16' (accuracy mode): storage type of the detector's weights / activations on the GPU.  The
+        """'fp16' (default) | 'bf16' (opt-in): storage type of the detector's weights / activations on the GPU.  The
         parameters themselves stay fp32 (checkpoint format unchanged); the engine is re-packed on the next forward."""
         if precision not in ops.STORAGE_TYPES:
             raise ValueError(f'precision must be one of {sorted(ops.STORAGE_TYPES)}, got {precision!r}')
@@ -699,7 +699,7 @@ def gln_backbone(trainable_layers=5, pretrained=True):
 
 def gln(num_classes=1, trainable_layers=4, pretrained_backbone=True, tanh=False, gaussian_loss_params={},
         detections_per_img=1000, precision=None):
-    """proposals.py:202-203 (+ `precision`, keyword-only in spirit: 'bf16' | 'fp16' storage of the detector on the GPU; None = the
-    CVPCE_DETECTOR_PRECISION environment variable, else 'bf16')"""
+    """proposals.py:202-203 (+ `precision`, keyword-only in spirit: 'fp16' | 'bf16' storage of the detector on the GPU; None = the
+    CVPCE_DETECTOR_PRECISION environment variable, else ops.DEFAULT_DETECTOR_PRECISION = 'fp16')"""
     return GaussianLayerNetwork(gln_backbone(trainable_layers, pretrained_backbone), num_classes, tanh=tanh,
                                 gaussian_loss_params=gaussian_loss_params, detections_per_img=detections_per_img, precision=precision)

@@ -19,6 +19,9 @@ from .torch_ops import T
 BF16 = torch.bfloat16
 F16 = torch.float16
 STORAGE_TYPES = {'bf16': BF16, 'fp16': F16}    # element types the detector's kernels exist for (csrc/common.h ElemBF16 / ElemF16)
+# the detector's default storage type: fp16 is the mode that meets north_star's 0.1 pt tolerance on AP50 / AP75 / AR300 / top-1
+# (profiles/r04_accuracy.json: bf16 misses it on AP75 and end-to-end top-1) at the same MFMA rate; bf16 is the opt-in
+DEFAULT_DETECTOR_PRECISION = 'fp16'
 F16_MAX = 65504.0
 
 
@@ -115,6 +118,7 @@ class ConvProfile:
 
     def __init__(self):
         self.records = []   # (variant, flops, start_event, end_event)
+        self.byte_records = []   # HBM-bound launches: (kernel, algorithmic bytes, start_event, end_event)
 
     @staticmethod
     def variant(pc, m):
@@ -145,7 +149,24 @@ class ConvProfile:
         return out
 
 
+    def summary_bytes(self):
+        """per HBM-bound kernel: launches, ALGORITHMIC bytes (every input and output tensor of the launch once, weights included) and
+        milliseconds -- bench.py `roofline.hbm_stages`."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, nbytes, e0, e1 in self.byte_records:
+            d = out.setdefault(name, {'launches': 0, 'bytes': 0.0, 'ms': 0.0})
+            d['launches'] += 1
+            d['bytes'] += float(nbytes)
+            d['ms'] += e0.elapsed_time(e1)
+        return out
+
+
 PROFILE = None   # set to a ConvProfile() to record
+
+
+def _nbytes(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 CONV1X1_ANY_SHAPE = bool(int(_os.environ.get('CVPCE_CONV1X1_ANY', '0')))   # test switch: every eligible 1x1 conv through the pointwise kernel
@@ -200,6 +221,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         if prof is not None:
             e1.record()
             prof.records.append(('thin3x3_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+            prof.byte_records.append(('thin3x3_kernel', _nbytes(x, out, pc.weight), e0, e1))
         return out
     # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
     if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
@@ -208,6 +230,8 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         if prof is not None:
             e1.record()
             prof.records.append(('conv1x1_kernel', 2.0 * n * ho * wo * pc.cout * pc.cin, e0, e1))
+            # a strided 1x1 reads only the pixels it keeps; an upsampled residual (res_mode 2) is read at its stored size
+            prof.byte_records.append(('conv1x1_kernel', n * ho * wo * cin * x.element_size() + _nbytes(out, residual, pc.weight), e0, e1))
         return out
     T.conv2d_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
                   int(act), int(out_f32), int(in_up_shift), int(res_mode), int(pool), int(FORCE_GENERIC_CONV))   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
@@ -550,6 +574,7 @@ def gauss_tail(x, c4, c5, act):
     if prof is not None:
         e1.record()
         prof.records.append(('gauss_tail_kernel', 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * (16 * 16 + 16), e0, e1))
+        prof.byte_records.append(('gauss_tail_kernel', _nbytes(x, out), e0, e1))
     return out
 
 
@@ -584,8 +609,15 @@ def gln_transform_batch(images, batch, sizes, mean, std):
     """images[i] (3,H0,W0) f32 cuda -> batch[i] (Hp,Wp,8), resized to sizes[i] = (h, w): the whole batch in one launch."""
     _need_cuda(batch, *images)
     assert batch.shape[0] == len(images) == len(sizes) and batch.shape[3] == 8 and batch.is_contiguous()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     T.gln_transform_batch([i.contiguous() for i in images], batch, [int(s[0]) for s in sizes], [int(s[1]) for s in sizes],
                           [float(v) for v in mean], [float(v) for v in std])
+    if prof is not None:
+        e1.record()
+        prof.byte_records.append(('gln_transform_batch_kernel', _nbytes(batch, *images), e0, e1))
 
 
 MAX_CROPS_PER_LAUNCH = 65535
@@ -604,13 +636,24 @@ def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, o
     assert out.shape[-1] == {0: size, 1: 8, 2: 4}[mode]
     m = [float(v) for v in mean] if mean is not None else None
     s = [float(v) for v in std] if std is not None else None
+    prof = PROFILE
     for start in range(0, p, MAX_CROPS_PER_LAUNCH):
         nb = min(MAX_CROPS_PER_LAUNCH, p - start)
         cnt = None
         if count is not None:
             assert start == 0 and p <= MAX_CROPS_PER_LAUNCH
             cnt = count
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         T.crop_resize(img, boxes[start:start + nb], cnt, out[start:start + nb], size, mode, m, s)
+        if prof is not None:
+            e1.record()
+            # algorithmic bytes: every source pixel of every (valid) box once (3 planes of f32) + the crops written
+            v = nb if cnt is None else int(cnt.reshape(-1)[0])
+            b = boxes[start:start + v].to(torch.long)
+            area = int(((b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)).sum())
+            prof.byte_records.append(('crop_resize_kernel', area * 3 * 4 + v * out[0].numel() * out.element_size(), e0, e1))
     return out
 
 

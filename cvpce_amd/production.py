@@ -383,10 +383,13 @@ class BatchedPipeline:
                 'indices': indices.view(n, dpi, k), 'gaussians': gauss, 'embeddings': emb, 'counts_host': counts}
 
     @torch.no_grad()
-    def run(self, images, stage_events=None):
+    def run(self, images, stage_events=None, proposals=None):
         """images: list of (3,H,W) f32 cuda tensors -> dict of device tensors:
         boxes (N,dpi,4), scores (N,dpi), count (N,) = #scores > confidence, indices (N,dpi,k) (-1 beyond count).
         stage_events: optional list that receives (stage name, start event, end event) for detect / crop / embed / match.
+        proposals: optional (boxes (N,dpi,4) f32, counts (N,) int32) device tensors that REPLACE the detector's confident boxes after
+        the detector has run (stage-isolated benchmarks accept planted proposals, which pins P and the box shapes
+        whatever the detector's weights emit); the detector's pass is still executed and timed.
         (Queueing the detector of call i + 1 on its own stream beside the embedder of call i was measured: +1.3 % at best, and
         the two stages' queues do not actually make progress side by side on this stack -- profiles/r03_rejected_experiments.md.)"""
         def mark():
@@ -399,6 +402,10 @@ class BatchedPipeline:
         det = self.detector
         t0 = mark()
         det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
+        if proposals is not None:
+            pb, pc = proposals
+            assert pb.shape == det_out[0].shape and pb.dtype == torch.float32 and pc.dtype == torch.int32 and pc.shape == det_out[4].shape
+            det_out = (pb, det_out[1], det_out[2], det_out[3], pc, det_out[5])
         t1 = mark()
         # The one host synchronisation of a step -- the confidence-prefix counts, which size the embedder's batch -- is
         # taken BESIDE the crop kernels, not before them: the counts go to pinned host memory right behind the detector,

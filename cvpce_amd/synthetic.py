@@ -21,7 +21,7 @@ def calibrate_head(model, logit_gain=8.0, logit_bias=1.0):
     return model
 
 
-def synthetic_gln(seed=0, detections_per_img=200, tanh=False, calibrate=True, residual_gain=1.0, precision='bf16'):
+def synthetic_gln(seed=0, detections_per_img=200, tanh=False, calibrate=True, residual_gain=1.0, precision=None):
     """Seeded GLN (CPU tensors; call .cuda() to run).
 
     residual_gain < 1 scales the last FrozenBN of every bottleneck (the residual branch's output gain).  Plain random init

@@ -43,7 +43,7 @@ import torch  # noqa: E402
 FITTED_HEAD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fitted_head.pt')
 
 
-def fitted_detector(detections_per_img, precision='bf16'):
+def fitted_detector(detections_per_img, precision=None):
     """The detector whose RetinaNet head was FITTED on structured shelf scenes (tests/golden/fit_head.py -> fitted_head.pt: the
     trained head tensors over the seeded base `synthetic_gln(seed=0, residual_gain=...)`): unlike the random-init detector it
     finds the products, so AP / AR against the TRUE boxes is a non-vacuous figure and its score field is bimodal like a trained
@@ -184,8 +184,8 @@ def _detection_report(hip, orc, shelves):
 
 @torch.no_grad()
 def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1024, oracle_device='cpu', match_dtypes=('bf16', 'f32'),
-        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None, precisions=('bf16',), detector='random'):
-    """precisions: detector storage modes to measure ('bf16' = the default schedule, 'fp16' = the accuracy mode); the oracle
+        k=5, images_per_batch=8, seed=0, control_images=0, residual_gain=1.0, log=None, precisions=('fp16',), detector='random'):
+    """precisions: detector storage modes to measure ('fp16' = the product default, 'bf16' = the opt-in); the oracle
     side is computed once.  The report's top-level `detection` / `matching` are those of precisions[0]; every mode's figures
     are under `by_precision`."""
     from cvpce_amd import ops, production, synthetic, datautils
@@ -353,7 +353,8 @@ def run(n_images=32, image_size=2048, galleries=(1000, 3200), dpi=200, queries=1
 
 
 def summary(report):
-    """The handful of figures bench.py puts into its `parity` object: top level = the first (default, bf16) detector precision,
+    """The handful of figures bench.py puts into its `parity` object: top level = the first detector precision of the report (bench.py
+    passes the mode of its run first: fp16, the product default),
     `by_precision` = the detector agreement of every measured mode."""
     def det(d):
         return {'ap50_vs_oracle': round(d['ap50_vs_oracle'], 4), 'ap50_area_vs_oracle': round(d['ap50_area_vs_oracle'], 4),
@@ -394,7 +395,7 @@ def main():
     ap.add_argument('--oracle-device', default='cpu', choices=['cpu', 'cuda'])
     ap.add_argument('--control-images', type=int, default=8, help='images of the bf16-emulation control (oracle/bf16_model.py)')
     ap.add_argument('--residual-gain', type=float, default=1.0, help='synthetic_gln residual_gain (conditioning of the random detector)')
-    ap.add_argument('--precisions', default='bf16,fp16', help="detector storage modes to measure (first = the report's top level)")
+    ap.add_argument('--precisions', default='fp16,bf16', help="detector storage modes to measure (first = the report's top level)")
     ap.add_argument('--detector', default='random', choices=['random', 'fitted'],
                     help='random = seeded random-init weights with the calibrated head; fitted = the head fitted on shelf scenes (tests/golden/fitted_head.pt)')
     ap.add_argument('--out', default=None)

@@ -96,3 +96,42 @@ def test_host_thread_share():
     per step: uncapped they would run 8 x cores OpenMP threads)."""
     import bench
     assert bench.host_threads_for(1, 64) == 64 and bench.host_threads_for(8, 64) == 8 and bench.host_threads_for(8, 4) == 1
+
+
+def _bench_stub(gpus, extra=()):
+    """`python bench.py --gpus N ...` exactly as a user (or the driver's launcher) starts it, with the CPU stand-in pipeline of
+    tests/bench_stub.py and the gloo backend: bench.py spawns torch.distributed.run as a child, N ranks run main()."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVPCE_BENCH_STUB='bench_stub:build', CVPCE_DIST_BACKEND='gloo', OMP_NUM_THREADS='1',
+               PYTHONPATH=os.pathsep.join([os.path.join(root, 'tests'), root, os.environ.get('PYTHONPATH', '')]))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '3', '--warmup', '1', '--gallery', '203',
+                        '--images-per-gpu', '8', '--verify', *extra], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+def test_bench_main_under_8_gloo_ranks():
+    """bench.py main() end to end under 8 ranks (BASELINE configs[4]'s layout: 8 images per rank, 64 in the job) with a CPU stand-in for the
+    HIP pipeline: argument parsing, launcher spawn, image sharding, the sharded gallery + ONE all_gather (uneven: 203 rows), three timed
+    windows with barriers and MAX-over-ranks, the --verify digest gather, rank 0's side legs not deadlocking the ranks that have none --
+    and the per-image digests are the ones a 1-rank and a 2-rank job compute for the same 64 / 16 global images."""
+    d8 = _bench_stub(8)
+    assert d8['n_gpus'] == 8 and d8['scaling'] == 'weak' and d8['steps'] == 3 and d8['config']['global_images'] == 64
+    assert d8['value'] > 0 and abs(d8['value'] - 64 * 3 / (d8['ms_per_step'] * 3e-3)) / d8['value'] < 1e-2       # whole-job images / max-over-ranks time
+    assert d8['windows']['n'] == 3
+    c = d8['config']['collectives']
+    assert c['backend'] == 'gloo' and c['world_size'] == 8 and c['all_gather'] == 1               # the process group saw 8 ranks; ONE gallery all_gather
+    assert c['all_gather_bytes_received'] == 8 * 26 * 16 * 4                                       # 8 padded blocks of ceil(203 / 8) = 26 rows x D x f32
+    assert c['in_timed_windows'] == {'all_gather': 0, 'all_reduce': 3, 'barrier': 6} and c['data_path_collectives_per_step'] == 0
+    v8 = d8['verify']
+    assert v8['images'] == 64 and sorted(int(g) for g in v8['per_image']) == list(range(64))
+    d2 = _bench_stub(2)
+    assert d2['n_gpus'] == 2 and d2['config']['collectives']['world_size'] == 2 and d2['verify']['images'] == 16
+    assert all(d2['verify']['per_image'][g] == v8['per_image'][g] for g in d2['verify']['per_image'])     # image g: same result at any world size

@@ -1,6 +1,7 @@
-"""End-to-end accuracy at the north-star tolerance: the whole HIP pipeline with the product defaults of bench.py (bf16
-activations, bf16 distance GEMM) against the whole fp32 oracle on structured shelf images -- tests/accuracy.py, the same
-code bench.py uses for its `parity` object.  Thresholds are the figures MEASURED on MI355X (full-size run:
+"""End-to-end accuracy at the north-star tolerance: the whole HIP pipeline with the product defaults of bench.py (detector storing
+fp16 -- the default since round 5, the mode that meets the 0.1 pt tolerance; bf16 embedder, bf16 distance GEMM) against the whole fp32
+oracle on structured shelf images -- tests/accuracy.py, the same code bench.py uses for its `parity` object.  The report's top level
+is the DEFAULT mode; the opt-in bf16 detector storage is measured beside it (`by_precision`).  Thresholds are the figures MEASURED on MI355X (full-size run:
 profiles/r02_accuracy.json) with head-room for the smaller sample used here; they replace round 1's 80 % / 5-point bounds.
 
 What the measurement shows (DESIGN.md "Accuracy"): the embed + match half of the path agrees with the fp32 oracle to the
@@ -23,11 +24,20 @@ def report(cuda):
     import accuracy                      # tests/accuracy.py
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     return accuracy.run(n_images=8, image_size=1024, galleries=(256,), dpi=200, queries=96, oracle_device='cpu',
-                        match_dtypes=('bf16', 'f32'), images_per_batch=8, control_images=4, precisions=('bf16', 'fp16'))
+                        match_dtypes=('bf16', 'f32'), images_per_batch=8, control_images=4, precisions=('fp16', 'bf16'))
+
+
+def test_default_mode_is_the_accuracy_mode(report):
+    """The product default (`gln()` without `precision`, bench.py without `--detector-precision`) is fp16 storage, and the report's top
+    level is that mode."""
+    from cvpce_amd import ops, synthetic
+    assert ops.DEFAULT_DETECTOR_PRECISION == 'fp16' and synthetic.synthetic_gln(seed=0, calibrate=False).precision == 'fp16'
+    assert report['detector_precisions'][0] == 'fp16' and report['detection'] is report['by_precision']['fp16']['detection']
 
 
 def test_detection_agreement(report):
-    d = report['detection']
+    """The opt-in bf16 detector storage on the random-weight detector: the floor of 7 mantissa bits, with its CPU-emulation control."""
+    d = report['by_precision']['bf16']['detection']
     assert d['oracle_boxes'] >= 8 * 150
     # the oracle's detections as ground truth: AP / AR300 of the HIP detections (cvpce/proposals_eval.py:19-48 metric code)
     assert d['ap50_vs_oracle'] > 0.84, d
@@ -60,7 +70,7 @@ def test_fp16_accuracy_mode_closes_the_detector_gap(report):
     assert f['ap50_vs_oracle'] >= 0.90, f                                  # the 11-point form, at its 10/11 ceiling
     assert f['paired_box_diff_px_mean'] < 0.3 and f['paired_abs_score_diff_mean'] < 2e-4, f
     assert abs(f['pseudo_gt']['delta_area_pt']) <= 1.5 < abs(b['pseudo_gt']['delta_area_pt']), (f['pseudo_gt'], b['pseudo_gt'])   # full size: -0.8 vs -4.7 pt
-    # and it is an improvement over the default mode on every agreement figure
+    # and it is an improvement over the bf16 storage on every agreement figure
     assert f['frac_oracle_boxes_iou90'] > b['frac_oracle_boxes_iou90'] + 0.03
     assert f['paired_box_diff_px_mean'] < 0.5 * b['paired_box_diff_px_mean']
     pb, pf = report['by_precision']['bf16']['matching_pairs'], report['by_precision']['fp16']['matching_pairs']
@@ -93,15 +103,16 @@ def fitted(cuda):
     import accuracy
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     return accuracy.run(n_images=8, image_size=1024, galleries=(256,), dpi=200, queries=96, oracle_device='cpu',
-                        match_dtypes=('bf16', 'f32'), images_per_batch=8, control_images=0, precisions=('bf16', 'fp16'), detector='fitted')
+                        match_dtypes=('bf16', 'f32'), images_per_batch=8, control_images=0, precisions=('fp16', 'bf16'), detector='fitted')
 
 
 def test_fitted_detector_map_against_true_boxes(fitted):
     """AP50 / AP75 / AR300 of the reference's metric code (cvpce/proposals_eval.py:19-48, cvpce/metrics.py:66-73,116-138) for the
-    HIP detector and for the fp32 oracle, both against the pasted products' true boxes: |delta| <= 0.1 pt in the fp16 accuracy
-    mode (north_star's tolerance); the default bf16 storage is within half a point (measured +0.21 / -0.19 / 0.0 pt here,
-    +0.01 / +0.14 / +0.03 pt on the 32 full-size scenes)."""
+    HIP detector and for the fp32 oracle, both against the pasted products' true boxes: |delta| <= 0.1 pt in the DEFAULT mode
+    (fp16 storage; north_star's tolerance) on AP50, AP75, AR300 and the all-point AP50; the opt-in bf16 storage is within half a point
+    (measured +0.21 / -0.19 / 0.0 pt here, +0.01 / +0.14 / +0.03 pt on the 32 full-size scenes)."""
     b, f = fitted['by_precision']['bf16']['detection'], fitted['by_precision']['fp16']['detection']
+    assert fitted['detection'] is f                                       # the report's top level = the default mode
     g = f['gt']
     assert g['true_boxes'] >= 200 and g['ap50_oracle'] >= 0.7 and g['ar300_oracle'] >= 0.9, g      # non-vacuous: the detector finds the products
     assert abs(g['delta_pt']) <= 0.1 and abs(g['delta75_pt']) <= 0.1 and abs(g['delta_ar300_pt']) <= 0.1, g

@@ -44,9 +44,12 @@ def test_pipeline_line_small(cuda):
     assert p['images'] == 4 and 0.5 < p['ap50_vs_oracle'] <= 1.0 and abs(p['G256_bf16']['top1_acc_delta_pt']) <= 2.0
     # round 4: the throughput in BOTH detector storage modes, executed vs algorithmic work, the fitted-detector parity against true boxes
     v = d['value_by_detector_precision']
-    assert v['bf16'] > 0 and v['fp16'] > 0 and abs(v['bf16'] - d['value']) < 1e-6
+    assert v['bf16'] > 0 and v['fp16'] > 0 and abs(v['fp16'] - d['value']) < 1e-6          # the headline runs in the DEFAULT mode: fp16
+    assert d['config']['detector_precision'] == 'fp16'
     g = r['gflop_per_step']
-    assert 0 < g['executed'] <= g['algorithmic'] and r['end_to_end']['executed_tflops'] <= r['end_to_end']['algorithmic_tflops']
+    assert 0 < g['executed'] <= g['algorithmic'] and r['end_to_end']['executed_tflops'] <= r['end_to_end']['images_equivalent_tflops']
+    assert 'algorithmic_tflops' not in r and all('algorithmic_tflops' not in e for e in r['all_conv_kernels'].values())
+    assert all(0 < e['frac_of_mfma_peak'] <= 1.0 for e in r['all_conv_kernels'].values())           # executed FLOPs cannot exceed the peak
     assert 0 < r['crop_shapes']['short_over_long_mean'] <= 1
     f = p['fitted_detector']
     assert f['true_boxes'] > 50 and set(f['by_precision']) == {'bf16', 'fp16'}
@@ -54,7 +57,20 @@ def test_pipeline_line_small(cuda):
     e = w['embed_planted_boxes']
     assert e['embed_ms_with_skipping'] < e['embed_ms_without'] and 0 < e['executed_over_algorithmic_flops'] < 1
     assert w['pipeline_fitted_scenes']['images_per_s'] > 0 and w['pipeline_fitted_scenes']['confident_boxes_per_image'] > 5
-
+    # round 5: co-headlines of the whole pipeline that do not depend on the random-weight detector's box shapes
+    co = d['co_headlines']
+    assert d['value_lists_off'] == co['lists_off']['images_per_s'] > 0 and co['lists_off']['executed_over_algorithmic_conv_flops'] == 1.0
+    assert d['value_planted_boxes'] == co['planted_boxes']['images_per_s'] > 0 and co['planted_boxes']['proposals_per_image'] == 200
+    assert 0.3 < co['planted_boxes']['short_over_long_mean'] < 0.9 and 0 < co['planted_boxes']['executed_over_algorithmic_conv_flops'] <= 1.0
+    assert d['value_fitted_scenes_p200'] == co['fitted_scenes_p200']['images_per_s'] > 0 and co['fitted_scenes_p200']['short_over_long_mean'] > 0.6
+    assert r['lists_off']['kernel'] == 'conv3x3_halo2_kernel' and 0 < r['lists_off']['frac'] <= 1.0
+    # round 5: the HBM-bound stages against the HBM roofline (algorithmic bytes, HIP-event time)
+    h = r['hbm_stages']
+    assert {'gln_transform_batch_kernel', 'crop_resize_kernel', 'conv1x1_kernel', 'thin3x3_kernel', 'gauss_tail_kernel'} <= set(h)
+    for name, e in h.items():
+        if not name.startswith('_'):
+            assert e['algorithmic_gb_per_step'] > 0 and e['ms_per_step'] > 0 and 0 < e['frac_of_hbm_peak'] <= 1.0, (name, e)
+    assert d['config']['collectives'] is None            # one rank, no process group
 
 def test_detector_and_match_stress_lines(cuda):
     d = _run('--workload', 'detector', '--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--no-cpu-baseline')
