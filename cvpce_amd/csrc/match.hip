@@ -66,6 +66,19 @@ extern "C" int cvpce_row_norms(const void* x, float* out, int rows, int D, int i
     return cvpce_check_launch();
 }
 
+// The distance of one (query, gallery row) pair from its dot product.  bf16 operands: 1 - dot * (1/|q| * 1/|g|), one multiply and one
+// fused multiply-add per pair with the two reciprocals formed once per row (a true division per pair is ~10 VALU instructions: in the
+// 256 x 320 tile's epilogue that was 160 divisions per lane, a fifth of the kernel).  Every bf16 kernel of this file forms the distance by
+// THIS expression from the same reciprocals, so a query's distances do not depend on the kernel that computed them.  f32 operands (the
+// reference's arithmetic): the literal 1 - dot / (|q| |g|).  `nq`, `ng`: the norm (F32) or its reciprocal (bf16), see match_norm_term.
+template <bool F32>
+__device__ __forceinline__ float match_distance(float dot, float nq, float ng) {
+    if constexpr (F32) return 1.f - dot / (nq * ng);
+    else return __builtin_fmaf(-dot, nq * ng, 1.f);
+}
+template <bool F32>
+__device__ __forceinline__ float match_norm_term(float norm) { return F32 ? norm : 1.f / norm; }
+
 // lexicographic (d, i) < (e, j)
 __device__ __forceinline__ bool lex_lt(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
 
@@ -247,14 +260,14 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
     float* s_gn = reinterpret_cast<float*>(smem + MT_TG * TQ * 4 + 2 * 256 * 4);      // the tile's 128 gallery norms (one coalesced load
     if (tid < MT_TG) {                                                                 // instead of 64 scattered ones per lane)
         const int gg = tile_g * MT_TG + tid;
-        s_gn[tid] = (gg < a.Gn) ? a.gn[gg] : 1.f;
+        s_gn[tid] = match_norm_term<F32>((gg < a.Gn) ? a.gn[gg] : 1.f);
     }
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int ql = wp * 32 * NT + nt * 32 + lr;
         const int qg = tile_q * TQ + ql;
-        const float qn = (qg < a.Qn) ? a.qn[qg] : 1.f;
+        const float qn = match_norm_term<F32>((qg < a.Qn) ? a.qn[qg] : 1.f);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
                 const int gg = tile_g * MT_TG + gl;
                 float d = INFINITY;
                 if (gg < a.Gn) {
-                    d = 1.f - acc[mt][nt][r] / (qn * s_gn[gl]);
+                    d = match_distance<F32>(acc[mt][nt][r], qn, s_gn[gl]);
                     if (!(d == d)) d = INFINITY;   // a NaN distance (non-finite embedding) sorts last and still yields a valid index
                 }
                 Tl[gl * TQ + ql] = d;
@@ -303,6 +316,256 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
             a.part_i[o] = bi;
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Large query batches (round 5; BASELINE configs[3] at 1 600 queries): a 256-gallery-row x (64 NQ)-query tile per workgroup of
+// EIGHT waves (4 along the gallery x 2 along the queries: a wave owns 64 gallery rows x 32 NQ queries = 2 x NQ accumulators of
+// v_mfma_f32_32x32x16_bf16), both operands brought in by LDS-DMA (`buffer_load_dwordx4 ... lds`: 8 neighbouring lanes fetch one
+// whole 128-byte line of a row; the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied to the SOURCE
+// address, the LDS image of a piece is lane-linear) into two 64-deep K-stages, ONE raw barrier per K-stage, and the hand-off
+// hidden behind MFMAs: the last of a stage's four 16-deep steps is multiplied AFTER the next stage's barrier, while that stage's
+// first fragments are on their way from LDS.  The 128 x 128 kernel above re-reads every operand byte twice as often from L2
+// (2 x (128 + 128) rows per 2 x 128 x 128 products against (256 + 320) rows per 256 x 320) and stages through registers + ds_write:
+// at 1 600 x 10 000 x 1 024 its K-steps are bound by that traffic (477 TFLOP/s).
+//
+// Every product is accumulated by the SAME instruction in the SAME K order as in `match_kernel` (32x32x16, 16-deep steps in
+// ascending K, one accumulator per (gallery row, query)), and the distance is formed by the same expression: a query's distances do
+// not depend on which of the kernels -- i.e. on how many queries it was batched with -- computed them.
+// The tile's k nearest rows per query are selected IN REGISTERS (a lane holds 32 gallery rows of each of its NQ queries, in
+// ascending row order), combined across the two lane halves by a lane exchange and across the four gallery waves through 10 KiB
+// of LDS; partials [Q][tiles_g][k] as above, merged by match_merge_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_m;
+typedef __attribute__((address_space(3))) char lds_char_m;
+#define MB_TG 256
+#define MB_ROWB 128                        // bytes of one row of a K-stage (64 bf16)
+
+template <int NQ>
+__global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
+    constexpr int TQ = 64 * NQ;
+    constexpr int STAGE = (MB_TG + TQ) * MB_ROWB;      // gallery rows, then query rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = wid >> 1, wq = wid & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    int tile_g, tile_q;
+    {   // XCD-aware order, as in match_kernel: an eighth of the gallery tiles per XCD, all their query tiles
+        int l = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+        int cls = 0, ng = (a.tiles_g + 7) >> 3;
+        while (cls < 7 && l >= ng * a.tiles_q) {
+            l -= ng * a.tiles_q;
+            ++cls;
+            ng = (a.tiles_g - cls + 7) >> 3;
+        }
+        tile_q = l / ng;
+        tile_g = cls + 8 * (l - tile_q * ng);
+    }
+    const unsigned rowbytes = (unsigned)a.D * 2u;
+    const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (unsigned)((size_t)a.Gn * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, (unsigned)((size_t)a.Qn * rowbytes), 0x00020000);
+
+    // DMA piece = 8 rows x 128 B; lane = 8 rr + p fills physical chunk p of row 8 piece + rr with the row's logical chunk
+    // p ^ ((row >> 1) & 7).  Wave w takes gallery pieces w, w + 8, w + 16, w + 24 and query pieces w + 8 j (j < NQ); rows beyond the
+    // matrix lie beyond the descriptor's range and arrive as zeros.
+    const int rr = lane >> 3, pch = lane & 7;
+    unsigned vg[4], vq[NQ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wid + 8 * j) * 8 + rr;
+        vg[j] = (unsigned)(tile_g * MB_TG + row) * rowbytes + (unsigned)((pch ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int row = (wid + 8 * j) * 8 + rr;
+        vq[j] = (unsigned)(tile_q * TQ + row) * rowbytes + (unsigned)((pch ^ ((row >> 1) & 7)) << 4);
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* dst = smem + buf * STAGE;
+        const int koff = kt * MB_ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_g, (lds_void_m*)(dst + (wid + 8 * j) * 1024), 16, (int)vg[j], koff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_q, (lds_void_m*)(dst + MB_TG * MB_ROWB + (wid + 8 * j) * 1024), 16, (int)vq[j], koff, 0, 0);
+    };
+
+    // fragment addresses: A block mg = gallery rows 64 wg + 32 mg + lr, B block nq = query rows 32 NQ wq + 32 nq + lr; the 16-deep step kk
+    // of a stage = logical chunks 2 kk + lh, physical chunk ^ ((row >> 1) & 7) = ^ ((lr >> 1) & 7) (the block bases are multiples of 16)
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_m*)smem;
+    const unsigned sw = (unsigned)((lr >> 1) & 7);
+    unsigned ca[4], cb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const unsigned co = ((unsigned)(2 * kk + lh) ^ sw) << 4;
+        ca[kk] = lds0 + (unsigned)((64 * wg + lr) * MB_ROWB) + co;
+        cb[kk] = lds0 + (unsigned)(MB_TG * MB_ROWB + (32 * NQ * wq + lr) * MB_ROWB) + co;
+    }
+
+    f32x16 acc[2][NQ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 fa[2][2], fb[2][NQ];            // two fragment sets: step s in set s & 1
+
+#define MB_READ(SET, KK, SOFF)                                                                                              \
+    {                                                                                                                       \
+        const unsigned a_ = ca[KK] + (SOFF), b_ = cb[KK] + (SOFF);                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                       \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[SET][i]) : "v"(a_), "n"(i * 32 * MB_ROWB));              \
+        _Pragma("unroll") for (int j = 0; j < NQ; ++j)                                                                      \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][j]) : "v"(b_), "n"(j * 32 * MB_ROWB));              \
+    }
+#define MB_MFMA(SET)                                                                                                        \
+    {                                                                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                       \
+            _Pragma("unroll") for (int j = 0; j < NQ; ++j)                                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);            \
+        __builtin_amdgcn_s_setprio(0);                                                                                      \
+    }
+    // ties the fragment registers of a set to the wait (the compiler must not move the MFMAs that read them above it)
+#define MB_WAIT(SET)                                                                                                        \
+    {                                                                                                                       \
+        if constexpr (NQ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]));             \
+        if constexpr (NQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2])); \
+        if constexpr (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3])); \
+        if constexpr (NQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3]), "+v"(fb[SET][4])); \
+    }
+
+    const int nk = a.D >> 6;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned soff = (unsigned)((kt & 1) * STAGE);
+        // stage kt has landed for this wave (its only loads in flight), and -- behind the barrier -- for every wave; every wave has
+        // also finished its fragment reads of stage kt - 1 (lgkmcnt(0) below), whose buffer the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        MB_READ(0, 0, soff)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt > 0) MB_MFMA(1)                           // step 3 of stage kt - 1: covers the barrier skew and the first reads' latency
+        __builtin_amdgcn_sched_barrier(0);
+        MB_WAIT(0)
+        MB_READ(1, 1, soff)
+        __builtin_amdgcn_sched_barrier(0);
+        MB_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        MB_WAIT(1)
+        MB_READ(0, 2, soff)
+        __builtin_amdgcn_sched_barrier(0);
+        MB_MFMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        MB_WAIT(0)
+        MB_READ(1, 3, soff)
+        __builtin_amdgcn_sched_barrier(0);
+        MB_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        MB_WAIT(1)                                       // step 3's fragments are in registers before the next barrier
+    }
+    MB_MFMA(1)
+#undef MB_READ
+#undef MB_MFMA
+#undef MB_WAIT
+
+    // ---- epilogue: per-query k smallest (distance, row) of this tile's 256 gallery rows --------------------------------------------
+    __builtin_amdgcn_s_barrier();                                   // every wave is past its last fragment read: the staging LDS is free
+    float* s_rg = reinterpret_cast<float*>(smem);                   // [256] 1 / |g| (NaN for rows past the gallery: never selected)
+    float* cd = reinterpret_cast<float*>(smem + 1024);              // [4][TQ] candidates of the four gallery waves
+    int* cix = reinterpret_cast<int*>(smem + 1024 + 4 * TQ * 4);
+    float* wd = reinterpret_cast<float*>(smem + 1024 + 8 * TQ * 4); // [TQ] the round's winner (k > 1: bounds the next round)
+    int* wix = reinterpret_cast<int*>(smem + 1024 + 9 * TQ * 4);
+    if (tid < MB_TG) {
+        const int gg = tile_g * MB_TG + tid;
+        s_rg[tid] = (gg < a.Gn) ? match_norm_term<false>(a.gn[gg]) : __builtin_nanf("");
+    }
+    __syncthreads();
+    float qnv[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        const int qg = tile_q * TQ + 32 * NQ * wq + 32 * nq + lr;
+        qnv[nq] = match_norm_term<false>((qg < a.Qn) ? a.qn[qg] : 1.f);
+    }
+    const int g0 = tile_g * MB_TG + 64 * wg + 4 * lh;               // gallery row of accumulator element (mg, e): g0 + 32 mg + (e & 3) + 8 (e >> 2)
+    float pd[NQ];
+    int pi[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) { pd[nq] = -INFINITY; pi[nq] = -1; }
+    for (int r = 0; r < a.k; ++r) {
+        float bd[NQ];
+        int bi[NQ];
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) { bd[nq] = INFINITY; bi[nq] = 0x7FFFFFFF; }
+        // (gallery rows in ascending order: mg, then e -- a lane keeps the lowest row among equal distances by strict comparison)
+#pragma unroll
+        for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 gn4 = *reinterpret_cast<const f32x4*>(s_rg + 64 * wg + 32 * mg + 8 * r4 + 4 * lh);   // this lane's four rows' norms
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int gi = g0 + 32 * mg + e4 + 8 * r4;
+                    // rows past the gallery (NaN norm) are never candidates; a NaN distance of a real row (non-finite embedding) sorts last
+                    const bool real = gn4[e4] == gn4[e4];
+#pragma unroll
+                    for (int nq = 0; nq < NQ; ++nq) {
+                        float d = match_distance<false>(acc[mg][nq][4 * r4 + e4], qnv[nq], gn4[e4]);
+                        d = (d == d) ? d : INFINITY;
+                        // branch-free (bitwise, not short-circuit): after the previous pick AND before the best so far.  gi ascends along the
+                        // scan, so "before the best" is d < best alone
+                        const bool after = (d > pd[nq]) | ((d == pd[nq]) & (gi > pi[nq]));
+                        const bool take = real & after & (d < bd[nq]);
+                        bd[nq] = take ? d : bd[nq];
+                        bi[nq] = take ? gi : bi[nq];
+                    }
+                }
+            }
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) {
+            // the other half of the wave holds the other 32 gallery rows of the same query
+            const float od = __shfl_xor(bd[nq], 32);
+            const int oi = __shfl_xor(bi[nq], 32);
+            if (lex_lt(od, oi, bd[nq], bi[nq])) { bd[nq] = od; bi[nq] = oi; }
+            if (lh == 0) {
+                cd[wg * TQ + 32 * NQ * wq + 32 * nq + lr] = bd[nq];
+                cix[wg * TQ + 32 * NQ * wq + 32 * nq + lr] = bi[nq];
+            }
+        }
+        __syncthreads();
+        if (tid < TQ) {
+            float bd = cd[tid];
+            int bi = cix[tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float od = cd[w * TQ + tid];
+                const int oi = cix[w * TQ + tid];
+                if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+            }
+            wd[tid] = bd;
+            wix[tid] = bi;
+            const int qg = tile_q * TQ + tid;
+            if (qg < a.Qn) {
+                const size_t o = ((size_t)qg * a.tiles_g + tile_g) * a.k + r;
+                a.part_d[o] = bd;
+                a.part_i[o] = bi;
+            }
+        }
+        if (r + 1 < a.k) {
+            __syncthreads();
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) {
+                pd[nq] = wd[32 * NQ * wq + 32 * nq + lr];
+                pi[nq] = wix[32 * NQ * wq + 32 * nq + lr];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -351,6 +614,17 @@ __global__ __launch_bounds__(256) void match_merge_kernel(const float* __restric
     }
 }
 
+// which bf16 core a launch takes: 0 = by the cost model below, 1 = always the 128-row kernel, 2 = always the 256-row LDS-DMA kernel;
+// g_match_nq = 2..5 pins the 256-row kernel's query-tile width (0 = by the model).  Test / measurement switch: results never depend on it.
+static int g_match_core = []() { const char* e = getenv("CVPCE_MATCH_CORE"); return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
+static int g_match_nq = []() { const char* e = getenv("CVPCE_MATCH_NQ"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 0; }();
+extern "C" int cvpce_match_set_core(int core, int nq) {
+    if (core < 0 || core > 2 || !(nq == 0 || (nq >= 2 && nq <= 5))) return CVPCE_ERR_ARG;
+    g_match_core = core;
+    g_match_nq = nq;
+    return CVPCE_OK;
+}
+
 extern "C" size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k) {
     const size_t tiles_g = (Gn + MT_TG - 1) / MT_TG;
     return (size_t)Qn * tiles_g * k * 8 + 512;
@@ -380,10 +654,46 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
         const double c128 = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 1.0, c64 = (double)((t64 + 3 * cus - 1) / (3 * cus)) * 0.6;
         tq = forced == 64 || forced == 128 ? forced : (c64 < c128 ? 64 : 128);
     }
-    a.tiles_q = (Qn + tq - 1) / tq;
+    // large query batches: the 256-row x 64 NQ-query LDS-DMA core (match_big_kernel), when its tiles fill the chip better per unit of
+    // work.  Cost model in units of one 128 x 128 tile-round of match_kernel (measured at 1 600 x 10 000 x 1 024, tools/dev/bench_match.py):
+    // a 256 x 64 NQ tile-round costs ~ 0.07 + 0.105 NQ.  Both kernels form identical distances, so the choice changes no result.
+    // (cvpce_match_set_core / CVPCE_MATCH_CORE = small | big forces one, CVPCE_MATCH_NQ = 2..5 the big tile's width: dev A/B)
+    int big_nq = 0;
+    if (!is_f32) {
+        const int core = g_match_core, forced_nq = g_match_nq;
+        const long long cus = g_cvpce_persistent_wgs;
+        const long long t128 = (long long)a.tiles_g * ((Qn + 127) / 128), t64 = (long long)a.tiles_g * ((Qn + 63) / 64);
+        double best = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 1.0;
+        const double c64 = (double)((t64 + 3 * cus - 1) / (3 * cus)) * 0.6;
+        if (c64 < best) best = c64;
+        const long long tg256 = (Gn + MB_TG - 1) / MB_TG;
+        double best_big = 1e30;
+        for (int nq = 2; nq <= 5; ++nq) {
+            if (forced_nq >= 2 && forced_nq <= 5 && nq != forced_nq) continue;
+            const long long t = tg256 * ((Qn + 64 * nq - 1) / (64 * nq));
+            const double c = (double)((t + cus - 1) / cus) * (0.07 + 0.105 * nq);
+            if (c < best_big) { best_big = c; big_nq = nq; }
+        }
+        if (core == 1 || (core == 0 && !(best_big < best))) big_nq = 0;
+    }
     a.part_d = (float*)workspace;
-    a.part_i = (int*)((char*)workspace + ((size_t)Qn * a.tiles_g * k * 4 + 255) / 256 * 256);
+    a.part_i = (int*)((char*)workspace + ((size_t)Qn * a.tiles_g * k * 4 + 255) / 256 * 256);    // (laid out for the 128-row tiling: enough for either)
     hipStream_t s = (hipStream_t)stream;
+    if (big_nq) {
+        a.tiles_g = (Gn + MB_TG - 1) / MB_TG;
+        a.tiles_q = (Qn + 64 * big_nq - 1) / (64 * big_nq);
+        if ((unsigned long long)((unsigned long long)Qn + 64 * big_nq) * D * 2 >= (1ull << 32) || ((unsigned long long)Gn + MB_TG) * D * 2 >= (1ull << 32)) return CVPCE_ERR_ARG;
+        const dim3 gridb(a.tiles_g * a.tiles_q);
+        const size_t smemb = (size_t)2 * (MB_TG + 64 * big_nq) * MB_ROWB;
+#define MB_LAUNCH(NQ_)                                                                                                         \
+        case NQ_:                                                                                                              \
+            if (!cvpce_smem_attr_done<match_big_kernel<NQ_>>((const void*)match_big_kernel<NQ_>, 2 * (MB_TG + 64 * NQ_) * MB_ROWB)) return CVPCE_ERR_LAUNCH; \
+            hipLaunchKernelGGL((match_big_kernel<NQ_>), gridb, dim3(512), smemb, s, a);                                        \
+            break;
+        switch (big_nq) { MB_LAUNCH(2) MB_LAUNCH(3) MB_LAUNCH(4) MB_LAUNCH(5) }
+#undef MB_LAUNCH
+    } else {
+    a.tiles_q = (Qn + tq - 1) / tq;
     dim3 grid(a.tiles_g * a.tiles_q);
     if (!cvpce_smem_attr_done<match_kernel<true, 128>>((const void*)match_kernel<true, 128>, 2 * 2 * 128 * 256) ||
         !cvpce_smem_attr_done<match_kernel<false, 128>>((const void*)match_kernel<false, 128>, 128 * 128 * 4 + 2048 + 512) ||
@@ -398,6 +708,7 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
     } else {
         size_t smem = (size_t)2 * (128 + 64) * 128;        // 48 KiB of staging dominates (epilogue image 32 KiB + 2.5 KiB)
         hipLaunchKernelGGL((match_kernel<false, 64>), grid, dim3(256), smem, s, a);
+    }
     }
     hipLaunchKernelGGL(match_merge_kernel, dim3((Qn + 3) / 4), dim3(256), 0, s, a.part_d, a.part_i, Qn, a.tiles_g * k,
                        k, out_idx, out_dist);

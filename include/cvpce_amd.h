@@ -275,6 +275,10 @@ size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k);
 int cvpce_match_topk(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
                      int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
                      long long* out_idx, float* out_dist, void* stream);
+/* Test / measurement switch of cvpce_match_topk's bf16 path (process-wide; results never depend on it: every bf16 kernel forms
+ * identical distances).  core 0 = choose per launch by tile count (default), 1 = the 128-row register-staged kernel, 2 = the
+ * 256-row LDS-DMA kernel for large query batches; nq = 0 | 2..5 pins that kernel's query tile to 64 nq rows. */
+int cvpce_match_set_core(int core, int nq);
 
 /* cvpce_conv3x3_halo_list's companion for a layer's STRIP list (Cout > 128 only): three listed tiles of which only the first 4
  * output rows are not constant are computed as ONE tile -- patch rows 6 s .. 6 s + 5 and accumulator rows 4 s .. 4 s + 3 belong to

@@ -40,7 +40,7 @@ def test_torch_ops_registered_for_the_gpu_only():
     """north_star: "exposed to Python through PyTorch-ROCm custom ops".  One dispatcher entry per C-ABI compute entry point,
     CUDA (= HIP) key only: a CPU tensor is refused by the dispatcher itself -- no CPU kernel exists to fall back to."""
     from cvpce_amd import torch_ops
-    declared = {s for s in header_symbols() if not s.endswith('_bytes') and s not in ('cvpce_set_persistent_workgroups', 'cvpce_pack_halo_weights')}   # (host-only helpers)
+    declared = {s for s in header_symbols() if not s.endswith('_bytes') and s not in ('cvpce_set_persistent_workgroups', 'cvpce_pack_halo_weights', 'cvpce_match_set_core')}   # (host-only helpers)
     # the fp16 twins of the detector's kernels (round 3) are reached through the SAME ops: the op picks the entry point by the
     # activations' dtype (torch_ops._by_dtype) -- every twin must have its bf16 original declared too
     twins = {s for s in declared if s.endswith('_f16')}

@@ -68,4 +68,5 @@ def test_rccl_collectives_execute_on_one_gpu(cuda):
                                     'WORLD_SIZE': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port())})
     assert rccl['n_gpus'] == 1 and rccl['value'] > 0
     assert rccl['verify']['per_image'] == plain['verify']['per_image'] and rccl['verify']['digest'] == plain['verify']['digest']
-    assert rccl['config'].get('collectives') == 'nccl'
+    c = rccl['config']['collectives']
+    assert c['backend'] == 'nccl' and c['world_size'] == 1 and c['all_gather'] == 1 and c['data_path_collectives_per_step'] == 0
