@@ -66,7 +66,10 @@ SIGNATURES = {
                                          _vp, c_size_t, _fp, _fp, _vp, _ip, _ip, _vp]),
     'cvpce_row_norms': (c_int, [_vp, _fp, c_int, c_int, c_int, c_float, _vp]),
     'cvpce_match_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'cvpce_match_set_core': (c_int, [c_int, c_int]),
+    'cvpce_match_set_core': (c_int, [c_int, c_int, c_int, c_int]),
+    'cvpce_match_state_bytes': (c_size_t, [c_int]),
+    'cvpce_match_state_init': (c_int, [_vp, c_size_t, _vp]),
+    'cvpce_match_topk_state': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _vp, c_size_t, _vp, c_size_t, _vp, _fp, _vp]),
     'cvpce_probe_l2_stream': (c_int, [_vp, c_longlong, c_int, _fp, c_int, _vp]),
     'cvpce_probe_mfma_bf16': (c_int, [c_int, c_int, _vp, _fp, c_int, _vp]),
     'cvpce_match_topk': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _vp, c_size_t, _vp, _fp, _vp]),

@@ -30,7 +30,22 @@ struct MatchArgs {
     const float* qn; const float* gn;     // L2 norms (already clamped by eps)
     int Qn, Gn, D, k, tiles_g, tiles_q;
     float* part_d; int* part_i;           // [Qn][tiles_g][k]
+    // one-launch form of match_big_kernel (k = 1): per-query 64-bit (distance, row) keys combined by agent-scope atomic minima, the
+    // last workgroup to finish (ticket) writes the results and restores the state block (cvpce_match_state_init)
+    unsigned long long* keys; int* ticket; long long* out_idx; float* out_dist;
 };
+
+// (distance, row) as ONE unsigned 64-bit key whose integer order is the lexicographic order: the float's bits made monotone
+// (negative: all bits flipped, non-negative: sign bit set) above the row index
+__device__ __forceinline__ unsigned long long match_key(float d, int i) {
+    const unsigned b = __float_as_uint(d);
+    const unsigned o = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned)i;
+}
+__device__ __forceinline__ float match_key_distance(unsigned long long key) {
+    const unsigned o = (unsigned)(key >> 32);
+    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
 
 __global__ void row_norm_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int D, float eps) {
     const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -339,13 +354,16 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_m;
 typedef __attribute__((address_space(3))) char lds_char_m;
-#define MB_TG 256
 #define MB_ROWB 128                        // bytes of one row of a K-stage (64 bf16)
 
-template <int NQ>
+// MG = gallery fragments (32 rows) per wave: the tile is TG = 128 MG gallery rows (MG = 2: the throughput form; MG = 1: twice the workgroups
+// for launches that would otherwise leave most CUs without a tile -- a few hundred queries, where the time is the per-CU operand intake)
+template <int NQ, int MG>
 __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
     constexpr int TQ = 64 * NQ;
-    constexpr int STAGE = (MB_TG + TQ) * MB_ROWB;      // gallery rows, then query rows
+    constexpr int TG = 128 * MG;
+    constexpr int GP = 2 * MG;                          // gallery DMA pieces per wave and stage (TG / 8 rows per piece / 8 waves)
+    constexpr int STAGE = (TG + TQ) * MB_ROWB;      // gallery rows, then query rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -371,28 +389,17 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
     // p ^ ((row >> 1) & 7).  Wave w takes gallery pieces w, w + 8, w + 16, w + 24 and query pieces w + 8 j (j < NQ); rows beyond the
     // matrix lie beyond the descriptor's range and arrive as zeros.
     const int rr = lane >> 3, pch = lane & 7;
-    unsigned vg[4], vq[NQ];
+    unsigned vg[GP], vq[NQ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < GP; ++j) {
         const int row = (wid + 8 * j) * 8 + rr;
-        vg[j] = (unsigned)(tile_g * MB_TG + row) * rowbytes + (unsigned)((pch ^ ((row >> 1) & 7)) << 4);
+        vg[j] = (unsigned)(tile_g * TG + row) * rowbytes + (unsigned)((pch ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int row = (wid + 8 * j) * 8 + rr;
         vq[j] = (unsigned)(tile_q * TQ + row) * rowbytes + (unsigned)((pch ^ ((row >> 1) & 7)) << 4);
     }
-    auto issue = [&](int kt, int buf) {
-        unsigned char* dst = smem + buf * STAGE;
-        const int koff = kt * MB_ROWB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_g, (lds_void_m*)(dst + (wid + 8 * j) * 1024), 16, (int)vg[j], koff, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_q, (lds_void_m*)(dst + MB_TG * MB_ROWB + (wid + 8 * j) * 1024), 16, (int)vq[j], koff, 0, 0);
-    };
-
     // fragment addresses: A block mg = gallery rows 64 wg + 32 mg + lr, B block nq = query rows 32 NQ wq + 32 nq + lr; the 16-deep step kk
     // of a stage = logical chunks 2 kk + lh, physical chunk ^ ((row >> 1) & 7) = ^ ((lr >> 1) & 7) (the block bases are multiples of 16)
     const unsigned lds0 = (unsigned)(size_t)(lds_char_m*)smem;
@@ -401,23 +408,23 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const unsigned co = ((unsigned)(2 * kk + lh) ^ sw) << 4;
-        ca[kk] = lds0 + (unsigned)((64 * wg + lr) * MB_ROWB) + co;
-        cb[kk] = lds0 + (unsigned)(MB_TG * MB_ROWB + (32 * NQ * wq + lr) * MB_ROWB) + co;
+        ca[kk] = lds0 + (unsigned)((32 * MG * wg + lr) * MB_ROWB) + co;
+        cb[kk] = lds0 + (unsigned)(TG * MB_ROWB + (32 * NQ * wq + lr) * MB_ROWB) + co;
     }
 
-    f32x16 acc[2][NQ];
+    f32x16 acc[MG][NQ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MG; ++i)
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    bf16x8 fa[2][2], fb[2][NQ];            // two fragment sets: step s in set s & 1
+    bf16x8 fa[2][MG], fb[2][NQ];            // two fragment sets: step s in set s & 1
 
 #define MB_READ(SET, KK, SOFF)                                                                                              \
     {                                                                                                                       \
         const unsigned a_ = ca[KK] + (SOFF), b_ = cb[KK] + (SOFF);                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                       \
+        _Pragma("unroll") for (int i = 0; i < MG; ++i)                                                                       \
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[SET][i]) : "v"(a_), "n"(i * 32 * MB_ROWB));              \
         _Pragma("unroll") for (int j = 0; j < NQ; ++j)                                                                      \
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[SET][j]) : "v"(b_), "n"(j * 32 * MB_ROWB));              \
@@ -425,38 +432,92 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
 #define MB_MFMA(SET)                                                                                                        \
     {                                                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                       \
+        _Pragma("unroll") for (int i = 0; i < MG; ++i)                                                                       \
             _Pragma("unroll") for (int j = 0; j < NQ; ++j)                                                                  \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);            \
         __builtin_amdgcn_s_setprio(0);                                                                                      \
     }
-    // ties the fragment registers of a set to the wait (the compiler must not move the MFMAs that read them above it)
+    // the wait, then every fragment register of the set tied to it (the compiler must not move the MFMAs that read them above the wait)
 #define MB_WAIT(SET)                                                                                                        \
     {                                                                                                                       \
-        if constexpr (NQ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]));             \
-        if constexpr (NQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2])); \
-        if constexpr (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3])); \
-        if constexpr (NQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3]), "+v"(fb[SET][4])); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MG; ++i) asm volatile("" : "+v"(fa[SET][i]));                                 \
+        _Pragma("unroll") for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(fb[SET][j]));                                 \
     }
 
+    // one DMA piece of stage KT: IDX 0..GP-1 = this wave's gallery pieces, GP.. = its query pieces
+    constexpr int NP = GP + NQ;
+    auto piece = [&](int kt, int buf, int idx) {
+        unsigned char* dst = smem + buf * STAGE;
+        const int koff = kt * MB_ROWB;
+        if (idx < GP) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_g, (lds_void_m*)(dst + (wid + 8 * idx) * 1024), 16, (int)vg[idx], koff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_q, (lds_void_m*)(dst + TG * MB_ROWB + (wid + 8 * (idx - GP)) * 1024), 16, (int)vq[idx - GP], koff, 0, 0);
+    };
+    // the MFMAs of one step with DMA pieces FIRST .. FIRST + COUNT - 1 of stage KT issued between them, one behind each MFMA: issuing a piece
+    // takes the wave ~60-100 clocks (MI355X_MICROARCH.md), which the matrix pipe spends on the MFMA just queued -- all nine pieces in a row
+    // right behind the barrier left the pipe idle for as long, in every wave at once
+#define MB_MFMA_DMA(SET, KT, BUF, FIRST, COUNT, MORE)                                                                       \
+    {                                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < MG; ++i)                                                                       \
+            _Pragma("unroll") for (int j = 0; j < NQ; ++j) {                                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);            \
+                __builtin_amdgcn_sched_barrier(0);                                                                          \
+                if (i * NQ + j < (COUNT) && (MORE)) piece(KT, BUF, (FIRST) + i * NQ + j);   /* (a scalar branch around one instruction) */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                          \
+            }                                                                                                               \
+    }
+    constexpr int PA = (NP + 1) / 2;       // pieces issued among the deferred MFMAs; the other NP - PA among step 0's
+    static_assert(PA <= MG * NQ && NP - PA <= MG * NQ, "one piece per MFMA");
+
     const int nk = a.D >> 6;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // two stages are in flight from the start (both buffers are free)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) piece(0, 0, i);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) piece(1, 1, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");      // stage 0 has landed for this wave; stage 1's pieces stay in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    MB_READ(0, 0, 0u)
+    MB_WAIT(0)
+    MB_READ(1, 1, 0u)
+    __builtin_amdgcn_sched_barrier(0);
+    MB_MFMA(0)
+    __builtin_amdgcn_sched_barrier(0);
+    MB_WAIT(1)
+    MB_READ(0, 2, 0u)
+    __builtin_amdgcn_sched_barrier(0);
+    MB_MFMA(1)
+    __builtin_amdgcn_sched_barrier(0);
+    MB_WAIT(0)
+    MB_READ(1, 3, 0u)
+    __builtin_amdgcn_sched_barrier(0);
+    MB_MFMA(0)
+    __builtin_amdgcn_sched_barrier(0);
+    MB_WAIT(1)
+    for (int kt = 1; kt < nk; ++kt) {
         const unsigned soff = (unsigned)((kt & 1) * STAGE);
+        const int nb = (kt + 1) & 1;
         // stage kt has landed for this wave (its only loads in flight), and -- behind the barrier -- for every wave; every wave has
-        // also finished its fragment reads of stage kt - 1 (lgkmcnt(0) below), whose buffer the next DMA overwrites
+        // also finished its fragment reads of stage kt - 1 (lgkmcnt(0) above), whose buffer the next DMA overwrites
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         MB_READ(0, 0, soff)
         __builtin_amdgcn_sched_barrier(0);
-        if (kt > 0) MB_MFMA(1)                           // step 3 of stage kt - 1: covers the barrier skew and the first reads' latency
+        // step 3 of stage kt - 1 (its fragments are in registers): covers the barrier skew, the first reads' latency and half of the
+        // next stage's DMA issue
+        const bool more = kt + 1 < nk;
+        MB_MFMA_DMA(1, kt + 1, nb, 0, PA, more)
         __builtin_amdgcn_sched_barrier(0);
         MB_WAIT(0)
         MB_READ(1, 1, soff)
         __builtin_amdgcn_sched_barrier(0);
-        MB_MFMA(0)
+        MB_MFMA_DMA(0, kt + 1, nb, PA, NP - PA, more)
         __builtin_amdgcn_sched_barrier(0);
         MB_WAIT(1)
         MB_READ(0, 2, soff)
@@ -471,6 +532,7 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
         MB_WAIT(1)                                       // step 3's fragments are in registers before the next barrier
     }
     MB_MFMA(1)
+#undef MB_MFMA_DMA
 #undef MB_READ
 #undef MB_MFMA
 #undef MB_WAIT
@@ -482,8 +544,8 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
     int* cix = reinterpret_cast<int*>(smem + 1024 + 4 * TQ * 4);
     float* wd = reinterpret_cast<float*>(smem + 1024 + 8 * TQ * 4); // [TQ] the round's winner (k > 1: bounds the next round)
     int* wix = reinterpret_cast<int*>(smem + 1024 + 9 * TQ * 4);
-    if (tid < MB_TG) {
-        const int gg = tile_g * MB_TG + tid;
+    if (tid < TG) {
+        const int gg = tile_g * TG + tid;
         s_rg[tid] = (gg < a.Gn) ? match_norm_term<false>(a.gn[gg]) : __builtin_nanf("");
     }
     __syncthreads();
@@ -493,7 +555,7 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
         const int qg = tile_q * TQ + 32 * NQ * wq + 32 * nq + lr;
         qnv[nq] = match_norm_term<false>((qg < a.Qn) ? a.qn[qg] : 1.f);
     }
-    const int g0 = tile_g * MB_TG + 64 * wg + 4 * lh;               // gallery row of accumulator element (mg, e): g0 + 32 mg + (e & 3) + 8 (e >> 2)
+    const int g0 = tile_g * TG + 32 * MG * wg + 4 * lh;               // gallery row of accumulator element (mg, e): g0 + 32 mg + (e & 3) + 8 (e >> 2)
     float pd[NQ];
     int pi[NQ];
 #pragma unroll
@@ -501,14 +563,39 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
     for (int r = 0; r < a.k; ++r) {
         float bd[NQ];
         int bi[NQ];
+        if (a.k == 1) {
+            // k = 1 (production.py's classify, the bench): one pass, five VALU instructions per pair (multiply, fused multiply-add,
+            // compare, two selects).  The candidate starts as (+inf, the lane's first row): a NaN distance (row past the gallery: NaN
+            // norm; non-finite embedding) compares false and is never taken, an all-NaN query keeps (+inf, first row) -- after the
+            // lexicographic combines below: the tile's first row, what the general scan and the 128-row kernel return for it
+#pragma unroll
+            for (int nq = 0; nq < NQ; ++nq) { bd[nq] = INFINITY; bi[nq] = g0; }
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 gn4 = *reinterpret_cast<const f32x4*>(s_rg + 32 * MG * wg + 32 * mg + 8 * r4 + 4 * lh);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int gi = g0 + 32 * mg + e4 + 8 * r4;
+#pragma unroll
+                        for (int nq = 0; nq < NQ; ++nq) {
+                            const float d = match_distance<false>(acc[mg][nq][4 * r4 + e4], qnv[nq], gn4[e4]);
+                            const bool take = d < bd[nq];
+                            bd[nq] = take ? d : bd[nq];
+                            bi[nq] = take ? gi : bi[nq];
+                        }
+                    }
+                }
+        } else {
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) { bd[nq] = INFINITY; bi[nq] = 0x7FFFFFFF; }
         // (gallery rows in ascending order: mg, then e -- a lane keeps the lowest row among equal distances by strict comparison)
 #pragma unroll
-        for (int mg = 0; mg < 2; ++mg)
+        for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 gn4 = *reinterpret_cast<const f32x4*>(s_rg + 64 * wg + 32 * mg + 8 * r4 + 4 * lh);   // this lane's four rows' norms
+                const f32x4 gn4 = *reinterpret_cast<const f32x4*>(s_rg + 32 * MG * wg + 32 * mg + 8 * r4 + 4 * lh);   // this lane's four rows' norms
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int gi = g0 + 32 * mg + e4 + 8 * r4;
@@ -521,12 +608,15 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
                         // branch-free (bitwise, not short-circuit): after the previous pick AND before the best so far.  gi ascends along the
                         // scan, so "before the best" is d < best alone
                         const bool after = (d > pd[nq]) | ((d == pd[nq]) & (gi > pi[nq]));
-                        const bool take = real & after & (d < bd[nq]);
+                        // (equal distances keep the lower row = the earlier one of this ascending scan; an all-infinite query -- non-finite
+                        // embedding -- must still pick its first admissible row: `bi` untouched means nothing was taken yet)
+                        const bool take = real & after & ((d < bd[nq]) | (bi[nq] == 0x7FFFFFFF));
                         bd[nq] = take ? d : bd[nq];
                         bi[nq] = take ? gi : bi[nq];
                     }
                 }
             }
+        }
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
             // the other half of the wave holds the other 32 gallery rows of the same query
@@ -552,10 +642,36 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
             wix[tid] = bi;
             const int qg = tile_q * TQ + tid;
             if (qg < a.Qn) {
-                const size_t o = ((size_t)qg * a.tiles_g + tile_g) * a.k + r;
-                a.part_d[o] = bd;
-                a.part_i[o] = bi;
+                if (a.keys) {
+                    // (the RETURNED old value makes the atomic's completion visible to this thread's vmcnt: it is performed -- at the
+                    // device's coherence point -- before the ticket below is drawn)
+                    const unsigned long long old = __hip_atomic_fetch_min(a.keys + qg, match_key(bd, bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::"v"(old));
+                } else {
+                    const size_t o = ((size_t)qg * a.tiles_g + tile_g) * a.k + r;
+                    a.part_d[o] = bd;
+                    a.part_i[o] = bi;
+                }
             }
+        }
+        if (a.keys) {
+            // ticket: the workgroup that finishes last has every tile's minima in `keys`; it writes the (Qn, 1) results and puts the
+            // state block back (keys all-ones, ticket 0) for the next launch on this state
+            int* s_last = reinterpret_cast<int*>(smem + 1024 + 10 * TQ * 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) *s_last = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*s_last == (int)gridDim.x - 1) {
+                for (int q = tid; q < a.Qn; q += 512) {
+                    const unsigned long long key = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.out_idx[q] = (long long)(unsigned)(key & 0xFFFFFFFFull);
+                    if (a.out_dist) a.out_dist[q] = match_key_distance(key);
+                    __hip_atomic_store(a.keys + q, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == 0) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
         }
         if (r + 1 < a.k) {
             __syncthreads();
@@ -617,12 +733,34 @@ __global__ __launch_bounds__(256) void match_merge_kernel(const float* __restric
 // which bf16 core a launch takes: 0 = by the cost model below, 1 = always the 128-row kernel, 2 = always the 256-row LDS-DMA kernel;
 // g_match_nq = 2..5 pins the 256-row kernel's query-tile width (0 = by the model).  Test / measurement switch: results never depend on it.
 static int g_match_core = []() { const char* e = getenv("CVPCE_MATCH_CORE"); return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
+// the one-launch form of cvpce_match_topk_state is OPT-IN: measured (tools/dev/bench_match.py) it loses to GEMM launch + merge launch wherever
+// the model picks the fastest tile -- 200 x 10 000 x 512: 10.4 us against 9.6 -- because every workgroup then ends with two dependent
+// device-scope atomic round trips (its keys, then the ticket) where the two-launch form ends with plain stores
+static int g_match_fused = []() { const char* e = getenv("CVPCE_MATCH_FUSED"); return e ? atoi(e) : 0; }();
+static int g_match_mg = []() { const char* e = getenv("CVPCE_MATCH_MG"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 0; }();
 static int g_match_nq = []() { const char* e = getenv("CVPCE_MATCH_NQ"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 5) ? v : 0; }();
-extern "C" int cvpce_match_set_core(int core, int nq) {
-    if (core < 0 || core > 2 || !(nq == 0 || (nq >= 2 && nq <= 5))) return CVPCE_ERR_ARG;
+extern "C" int cvpce_match_set_core(int core, int nq, int mg, int one_launch) {
+    if (core < 0 || core > 2 || !(nq == 0 || (nq >= 2 && nq <= 5)) || mg < 0 || mg > 2 || (mg == 1 && nq == 5)) return CVPCE_ERR_ARG;
     g_match_core = core;
     g_match_nq = nq;
+    g_match_mg = mg;
+    g_match_fused = one_launch != 0;
     return CVPCE_OK;
+}
+
+// ---- state block of the one-launch top-1 form: `max_queries` 64-bit keys (all-ones = no candidate yet) + the ticket counter -----------
+__global__ void match_state_init_kernel(unsigned long long* keys, int n_keys, int* ticket) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_keys) keys[i] = ~0ull;
+    if (i == 0) *ticket = 0;
+}
+extern "C" size_t cvpce_match_state_bytes(int max_queries) { return max_queries <= 0 ? 0 : (size_t)max_queries * 8 + 64; }
+extern "C" int cvpce_match_state_init(void* state, size_t state_bytes, void* stream) {
+    if (!state || state_bytes < 64 + 8 || ((size_t)state & 7)) return CVPCE_ERR_ARG;
+    const int n = (int)((state_bytes - 64) / 8);
+    hipLaunchKernelGGL(match_state_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)state, n,
+                       (int*)((char*)state + (size_t)n * 8));
+    return cvpce_check_launch();
 }
 
 extern "C" size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k) {
@@ -630,9 +768,25 @@ extern "C" size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k) {
     return (size_t)Qn * tiles_g * k * 8 + 512;
 }
 
+static int match_topk_impl(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
+                           int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
+                           void* state, size_t state_bytes, long long* out_idx, float* out_dist, void* stream);
+
 extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
                                 int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
                                 long long* out_idx, float* out_dist, void* stream) {
+    return match_topk_impl(queries, gallery, q_norms, g_norms, Qn, Gn, D, k, is_f32, workspace, workspace_bytes, nullptr, 0, out_idx, out_dist, stream);
+}
+extern "C" int cvpce_match_topk_state(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
+                                      int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
+                                      void* state, size_t state_bytes, long long* out_idx, float* out_dist, void* stream) {
+    if (state && (state_bytes < 64 + 8 || ((size_t)state & 7))) return CVPCE_ERR_ARG;
+    return match_topk_impl(queries, gallery, q_norms, g_norms, Qn, Gn, D, k, is_f32, workspace, workspace_bytes, state, state_bytes, out_idx, out_dist, stream);
+}
+
+static int match_topk_impl(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
+                           int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
+                           void* state, size_t state_bytes, long long* out_idx, float* out_dist, void* stream) {
     if (!queries || !gallery || !q_norms || !g_norms || !workspace || !out_idx) return CVPCE_ERR_ARG;
     if (D <= 0 || D % MT_BK != 0 || k < 1 || k > MATCH_KMAX || Gn < k) return CVPCE_ERR_ARG;
     if (Qn <= 0) return CVPCE_OK;
@@ -643,6 +797,7 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
     }
     MatchArgs a;
     a.q = queries; a.g = gallery; a.qn = q_norms; a.gn = g_norms; a.Qn = Qn; a.Gn = Gn; a.D = D; a.k = k;
+    a.keys = nullptr; a.ticket = nullptr; a.out_idx = out_idx; a.out_dist = out_dist;
     a.tiles_g = (Gn + MT_TG - 1) / MT_TG;
     // query tile of the bf16 kernel: 64-query tiles cost ~0.6 of a 128-query tile and run three to a CU instead of two; the
     // cheaper schedule in whole rounds of the chip wins (CVPCE_MATCH_TQ = 64 | 128 forces one: dev A/B)
@@ -654,44 +809,65 @@ extern "C" int cvpce_match_topk(const void* queries, const void* gallery, const 
         const double c128 = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 1.0, c64 = (double)((t64 + 3 * cus - 1) / (3 * cus)) * 0.6;
         tq = forced == 64 || forced == 128 ? forced : (c64 < c128 ? 64 : 128);
     }
-    // large query batches: the 256-row x 64 NQ-query LDS-DMA core (match_big_kernel), when its tiles fill the chip better per unit of
-    // work.  Cost model in units of one 128 x 128 tile-round of match_kernel (measured at 1 600 x 10 000 x 1 024, tools/dev/bench_match.py):
-    // a 256 x 64 NQ tile-round costs ~ 0.07 + 0.105 NQ.  Both kernels form identical distances, so the choice changes no result.
-    // (cvpce_match_set_core / CVPCE_MATCH_CORE = small | big forces one, CVPCE_MATCH_NQ = 2..5 the big tile's width: dev A/B)
-    int big_nq = 0;
+    // Which bf16 core and tile: the LDS-DMA kernel (match_big_kernel, 128 MG gallery rows x 64 NQ queries per workgroup) or the 128-row
+    // register-staged one, by estimated time.  Model (microseconds; least-squares fit to tools/dev/bench_match.py on MI355X, 63 launches of
+    // 200 ... 3 200 queries x 1 000 ... 10 000 rows x 512 | 1 024, rms error 8 %, picks the fastest variant or one within 1 % of it on all nine
+    // shapes):  launch = fixed + rounds x (D / 512) x round, where a round's cost grows with the share u of the CUs that hold a tile in it
+    // (L2 intake and clocks):
+    //   LDS-DMA kernel:   fixed 3.9 + 0.48 NQ,  round (0.74 + 1.97 NQ) x (MG = 1 ? 0.575 : 1) x (1 + 0.75 u)
+    //   128-row kernel:   fixed 10.4,           round 5.4 x (1 + 0.75 u) (64-query tiles, three per CU) | 9.0 x (1 + 0.75 u) (128-query, two per CU)
+    // Every bf16 kernel forms identical distances, so the choice changes no result (cvpce_match_set_core / CVPCE_MATCH_CORE = small | big,
+    // CVPCE_MATCH_NQ = 2..5, CVPCE_MATCH_MG = 1 | 2 force one: tests and A/B measurements).
+    int big_nq = 0, big_mg = 2;
     if (!is_f32) {
         const int core = g_match_core, forced_nq = g_match_nq;
         const long long cus = g_cvpce_persistent_wgs;
+        const double dk = (double)D / 512.0;
         const long long t128 = (long long)a.tiles_g * ((Qn + 127) / 128), t64 = (long long)a.tiles_g * ((Qn + 63) / 64);
-        double best = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 1.0;
-        const double c64 = (double)((t64 + 3 * cus - 1) / (3 * cus)) * 0.6;
-        if (c64 < best) best = c64;
-        const long long tg256 = (Gn + MB_TG - 1) / MB_TG;
+        const long long r128 = (t128 + 2 * cus - 1) / (2 * cus), r64 = (t64 + 3 * cus - 1) / (3 * cus);
+        const double e128 = 10.4 + (double)r128 * dk * 9.0 * (1.0 + 0.75 * (double)t128 / (double)(r128 * 2 * cus));
+        const double e64 = 10.4 + (double)r64 * dk * 5.4 * (1.0 + 0.75 * (double)t64 / (double)(r64 * 3 * cus));
+        const double best = e64 < e128 ? e64 : e128;
         double best_big = 1e30;
-        for (int nq = 2; nq <= 5; ++nq) {
-            if (forced_nq >= 2 && forced_nq <= 5 && nq != forced_nq) continue;
-            const long long t = tg256 * ((Qn + 64 * nq - 1) / (64 * nq));
-            const double c = (double)((t + cus - 1) / cus) * (0.07 + 0.105 * nq);
-            if (c < best_big) { best_big = c; big_nq = nq; }
-        }
-        if (core == 1 || (core == 0 && !(best_big < best))) big_nq = 0;
+        for (int mg = 1; mg <= 2; ++mg)
+            for (int nq = 2; nq <= 5; ++nq) {
+                if ((forced_nq && nq != forced_nq) || (g_match_mg && mg != g_match_mg) || (mg == 1 && nq == 5)) continue;
+                const long long t = (long long)((Gn + 128 * mg - 1) / (128 * mg)) * ((Qn + 64 * nq - 1) / (64 * nq)), rounds = (t + cus - 1) / cus;
+                const double u = (double)t / (double)(rounds * cus);
+                const double e = 3.9 + 0.48 * nq + (double)rounds * dk * (0.74 + 1.97 * nq) * (mg == 1 ? 0.575 : 1.0) * (1.0 + 0.75 * u);
+                if (e < best_big) { best_big = e; big_nq = nq; big_mg = mg; }
+            }
+        // (a handful of queries against a small gallery is launch latency either way: the 128-row kernel keeps those)
+        if (core == 1 || (core == 0 && (!(best_big < best) || (long long)Qn * Gn < 64 * 1024))) big_nq = 0;
     }
     a.part_d = (float*)workspace;
     a.part_i = (int*)((char*)workspace + ((size_t)Qn * a.tiles_g * k * 4 + 255) / 256 * 256);    // (laid out for the 128-row tiling: enough for either)
     hipStream_t s = (hipStream_t)stream;
     if (big_nq) {
-        a.tiles_g = (Gn + MB_TG - 1) / MB_TG;
+        const int tg = 128 * big_mg;
+        a.tiles_g = (Gn + tg - 1) / tg;
         a.tiles_q = (Qn + 64 * big_nq - 1) / (64 * big_nq);
-        if ((unsigned long long)((unsigned long long)Qn + 64 * big_nq) * D * 2 >= (1ull << 32) || ((unsigned long long)Gn + MB_TG) * D * 2 >= (1ull << 32)) return CVPCE_ERR_ARG;
+        if ((unsigned long long)((unsigned long long)Qn + 64 * big_nq) * D * 2 >= (1ull << 32) || ((unsigned long long)Gn + tg) * D * 2 >= (1ull << 32)) return CVPCE_ERR_ARG;
         const dim3 gridb(a.tiles_g * a.tiles_q);
-        const size_t smemb = (size_t)2 * (MB_TG + 64 * big_nq) * MB_ROWB;
-#define MB_LAUNCH(NQ_)                                                                                                         \
-        case NQ_:                                                                                                              \
-            if (!cvpce_smem_attr_done<match_big_kernel<NQ_>>((const void*)match_big_kernel<NQ_>, 2 * (MB_TG + 64 * NQ_) * MB_ROWB)) return CVPCE_ERR_LAUNCH; \
-            hipLaunchKernelGGL((match_big_kernel<NQ_>), gridb, dim3(512), smemb, s, a);                                        \
+        // k = 1 with a state block that holds a key per query: ONE launch (no partials, no merge kernel)
+        const int n_keys = state ? (int)((state_bytes - 64) / 8) : 0;
+        const bool fused = state && k == 1 && Qn <= n_keys && g_match_fused;
+        if (fused) {
+            a.keys = (unsigned long long*)state;
+            a.ticket = (int*)((char*)state + (size_t)n_keys * 8);
+        }
+        const size_t smemb = (size_t)2 * (tg + 64 * big_nq) * MB_ROWB;
+#define MB_LAUNCH(NQ_, MG_)                                                                                                    \
+        case NQ_ * 4 + MG_:                                                                                                    \
+            if (!cvpce_smem_attr_done<match_big_kernel<NQ_, MG_>>((const void*)match_big_kernel<NQ_, MG_>, 2 * (128 * MG_ + 64 * NQ_) * MB_ROWB)) return CVPCE_ERR_LAUNCH; \
+            hipLaunchKernelGGL((match_big_kernel<NQ_, MG_>), gridb, dim3(512), smemb, s, a);                                   \
             break;
-        switch (big_nq) { MB_LAUNCH(2) MB_LAUNCH(3) MB_LAUNCH(4) MB_LAUNCH(5) }
+        switch (big_nq * 4 + big_mg) {
+            MB_LAUNCH(2, 2) MB_LAUNCH(3, 2) MB_LAUNCH(4, 2) MB_LAUNCH(5, 2) MB_LAUNCH(2, 1) MB_LAUNCH(3, 1) MB_LAUNCH(4, 1)
+            default: return CVPCE_ERR_ARG;
+        }
 #undef MB_LAUNCH
+        if (fused) return cvpce_check_launch();
     } else {
     a.tiles_q = (Qn + tq - 1) / tq;
     dim3 grid(a.tiles_g * a.tiles_q);

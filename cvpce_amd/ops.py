@@ -750,8 +750,28 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
     dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
     ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
-    T.match_topk(queries, gallery, q_norms, g_norms, k, ws, idx, dist)
+    if k == 1 and queries.dtype == BF16 and qn <= MATCH_STATE_QUERIES:
+        # the one-launch form: a state block per (device, stream) -- launches of one stream are ordered, so they can share a block
+        T.match_topk_state(queries, gallery, q_norms, g_norms, k, ws, match_state(queries.device), idx, dist)
+    else:
+        T.match_topk(queries, gallery, q_norms, g_norms, k, ws, idx, dist)
     return (idx, dist) if return_distance else idx
+
+
+MATCH_STATE_QUERIES = 16384      # queries per launch the one-launch top-1 search holds keys for (128 KiB per state block)
+_MATCH_STATE = {}
+
+
+def match_state(device):
+    """The persistent state block of the one-launch top-1 search for the CURRENT stream of `device` (include/cvpce_amd.h
+    cvpce_match_topk_state): initialised once, restored by every launch that uses it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    st = _MATCH_STATE.get(key)
+    if st is None:
+        st = torch.empty(lib.cvpce_match_state_bytes(MATCH_STATE_QUERIES) // 8, dtype=torch.int64, device=device)
+        T.match_state_init(st)
+        _MATCH_STATE[key] = st
+    return st
 
 
 def pad_features(x, multiple=64):

@@ -320,6 +320,20 @@ def _match_topk(queries, gallery, q_norms, g_norms, k, workspace, idx, dist):
           'cvpce_match_topk')
 
 
+@_op('match_topk_state(Tensor queries, Tensor gallery, Tensor q_norms, Tensor g_norms, int k, Tensor(a!) workspace, Tensor(b!) state, '
+     'Tensor(c!) idx, Tensor(d!)? dist) -> ()')
+def _match_topk_state(queries, gallery, q_norms, g_norms, k, workspace, state, idx, dist):
+    check(lib.cvpce_match_topk_state(_p(queries), _p(gallery), _p(q_norms), _p(g_norms), queries.shape[0], gallery.shape[0], queries.shape[1], k,
+                                     int(queries.dtype == torch.float32), _p(workspace), workspace.numel(), _p(state), state.numel() * state.element_size(),
+                                     _p(idx), _p(dist), _stream()),
+          'cvpce_match_topk_state')
+
+
+@_op('match_state_init(Tensor(a!) state) -> ()')
+def _match_state_init(state):
+    check(lib.cvpce_match_state_init(_p(state), state.numel() * state.element_size(), _stream()), 'cvpce_match_state_init')
+
+
 @_op('probe_mfma_bf16(int shape, int iters, Tensor operands, Tensor(a!) sink, int workgroups) -> ()')
 def _probe_mfma_bf16(shape, iters, operands, sink, workgroups):
     check(lib.cvpce_probe_mfma_bf16(shape, iters, _p(operands), _p(sink), workgroups, _stream()), 'probe')

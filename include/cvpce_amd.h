@@ -275,10 +275,23 @@ size_t cvpce_match_workspace_bytes(int Qn, int Gn, int k);
 int cvpce_match_topk(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
                      int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
                      long long* out_idx, float* out_dist, void* stream);
-/* Test / measurement switch of cvpce_match_topk's bf16 path (process-wide; results never depend on it: every bf16 kernel forms
- * identical distances).  core 0 = choose per launch by tile count (default), 1 = the 128-row register-staged kernel, 2 = the
- * 256-row LDS-DMA kernel for large query batches; nq = 0 | 2..5 pins that kernel's query tile to 64 nq rows. */
-int cvpce_match_set_core(int core, int nq);
+/* The same with a caller-owned STATE block (cvpce_match_state_bytes(max_queries) bytes, 8-byte aligned, initialised ONCE by
+ * cvpce_match_state_init and restored by every call that uses it): with k = 1, bf16 rows and Qn <= max_queries the whole search is ONE
+ * launch -- per-query 64-bit (distance, row) keys combined by device-scope atomic minima, results written by the last workgroup to
+ * finish -- instead of a GEMM launch + a merge launch.  One state block per launch that may be in flight at a time (two streams: two
+ * blocks).  state = NULL, k > 1, f32 rows or a query count beyond the block: exactly cvpce_match_topk.  Identical results either way.
+ * OPT-IN (cvpce_match_set_core(..., one_launch = 1) or CVPCE_MATCH_FUSED=1): measured slower than the two launches at every size
+ * (200 x 10 000 x 512: 10.4 us against 9.6 us), so by default this entry point IS cvpce_match_topk. */
+size_t cvpce_match_state_bytes(int max_queries);
+int cvpce_match_state_init(void* state, size_t state_bytes, void* stream);
+int cvpce_match_topk_state(const void* queries, const void* gallery, const float* q_norms, const float* g_norms,
+                           int Qn, int Gn, int D, int k, int is_f32, void* workspace, size_t workspace_bytes,
+                           void* state, size_t state_bytes, long long* out_idx, float* out_dist, void* stream);
+/* Test / measurement switch of the bf16 path (process-wide; results never depend on it: every bf16 kernel forms identical
+ * distances).  core 0 = choose per launch by estimated time (default), 1 = the 128-row register-staged kernel, 2 = the 256-row
+ * LDS-DMA kernel; nq = 0 | 2..5 pins that kernel's query tile to 64 nq rows, mg = 0 | 1 | 2 its gallery tile to 128 mg rows
+ * (mg = 1 exists for nq <= 4); one_launch = 0 keeps cvpce_match_topk_state on the two-launch form. */
+int cvpce_match_set_core(int core, int nq, int mg, int one_launch);
 
 /* cvpce_conv3x3_halo_list's companion for a layer's STRIP list (Cout > 128 only): three listed tiles of which only the first 4
  * output rows are not constant are computed as ONE tile -- patch rows 6 s .. 6 s + 5 and accumulator rows 4 s .. 4 s + 3 belong to

@@ -496,6 +496,43 @@ def test_match_parity(cuda, dtype, qn, gn, d, k):
     torch.testing.assert_close(dist.cpu(), ref_d.gather(1, idx.cpu()), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize('qn,gn,d', [(200, 10000, 512), (1600, 10000, 1024), (333, 1357, 256), (5, 40, 64)])
+def test_match_every_core_and_tile_gives_identical_results(cuda, qn, gn, d):
+    """The bf16 search has two cores (the 128-row register-staged kernel; the LDS-DMA kernel of round 5 with tiles of 128 MG gallery rows x
+    64 NQ queries) and, opt-in, a one-launch form of k = 1 (atomic (distance, row) keys + ticket).  Which one a launch takes is a cost
+    model's choice, so every variant must return the SAME indices and the SAME distances bit for bit -- a query's result must not depend
+    on how many queries it was batched with (classification.py:87-95; BASELINE configs[3] sizes first).  Includes a NaN query, equal rows
+    (ties -> lower index), a ragged last tile in both dimensions, k = 1 and k = 4, and a second call on the restored state block."""
+    from cvpce_amd import ops
+    from cvpce_amd._lib import lib
+    g = torch.Generator().manual_seed(qn * 7 + gn)
+    G = F.normalize(torch.rand(gn, d, generator=g), dim=1)
+    Q = F.normalize(torch.rand(qn, d, generator=g), dim=1)
+    G[gn // 2] = G[3]                                    # duplicate rows: a tie for every query
+    Q[1, 5] = float('nan')
+    Gd, Qd = G.to(torch.bfloat16).to(cuda), Q.to(torch.bfloat16).to(cuda)
+    variants = [(1, 0, 0, 0)] + [(2, nq, mg, one) for mg in (1, 2) for nq in (2, 3, 4, 5) if not (mg == 1 and nq == 5) for one in (0, 1)]
+    ref = None
+    try:
+        for core, nq, mg, one in variants:
+            assert lib.cvpce_match_set_core(core, nq, mg, one) == 0
+            got = [ops.match_topk(Qd, Gd, 4, return_distance=True), ops.match_topk(Qd, Gd, 1, return_distance=True),
+                   ops.match_topk(Qd, Gd, 1, return_distance=True)]
+            torch.cuda.synchronize()
+            got = [(i.cpu(), x.cpu()) for i, x in got]
+            assert int(got[0][0].min()) >= 0 and int(got[0][0].max()) < gn
+            assert got[1][0].equal(got[0][0][:, :1]) and got[2][0].equal(got[1][0]) and got[2][1].equal(got[1][1])
+            if ref is None:
+                ref = got
+            for (i, x), (ri, rx) in zip(got, ref):
+                assert i.equal(ri), (core, nq, mg, one)
+                assert torch.equal(x.view(torch.int32), rx.view(torch.int32)), (core, nq, mg, one)       # bit for bit (inf rows included)
+    finally:
+        lib.cvpce_match_set_core(0, 0, 0, 0)
+    assert ref[0][0][1].tolist() == [0, 1, 2, 3]                                      # the NaN query: all distances +inf, lowest rows first
+    assert lib.cvpce_match_set_core(2, 5, 1, 0) == 1 and lib.cvpce_match_set_core(3, 0, 0, 0) == 1      # no 128-row x 320-query tile; no such core
+
+
 def test_match_k_clamped_and_nan_rows(cuda):
     """classification.py:95 `argsort[:, :k]` returns min(k, G) columns; a query with a non-finite embedding still gets valid
     gallery indices (NaN distances sort last), so `annotations[j]` lookups never go out of range."""

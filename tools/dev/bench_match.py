@@ -39,15 +39,25 @@ for P, G, D in cases:
     q = torch.nn.functional.normalize(torch.randn(P, D, generator=torch.Generator().manual_seed(1)), dim=1).to(dev).to(torch.bfloat16)
     gn, qn = ops.row_norms(gal), ops.row_norms(q)
     res = {}
-    ref = None
-    for name, core, nq in (('auto', 0, 0), ('small', 1, 0), ('big2', 2, 2), ('big3', 2, 3), ('big4', 2, 4), ('big5', 2, 5)):
-        assert lib.cvpce_match_set_core(core, nq) == 0
+    ref = ref1 = None
+    variants = [('auto', 0, 0, 0, 0), ('small', 1, 0, 0, 0)]
+    for mg in (1, 2):
+        for nq in (2, 3, 4, 5):
+            if mg == 1 and nq == 5:
+                continue
+            variants += [(f'b{nq}x{mg}', 2, nq, mg, 0), (f'b{nq}x{mg}-1L', 2, nq, mg, 1)]
+    for name, core, nq, mg, one in variants:
+        assert lib.cvpce_match_set_core(core, nq, mg, one) == 0
         idx, dist = ops.match_topk(q, gal, 3, q_norms=qn, g_norms=gn, return_distance=True)
+        idx1, dist1 = ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn, return_distance=True)      # (k = 1: the one-launch form where enabled)
+        idx1b, dist1b = ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn, return_distance=True)    # ... and again on the restored state block
         torch.cuda.synchronize()
         if ref is None:
-            ref = (idx.clone(), dist.clone())
-        same = bool(torch.equal(idx, ref[0]) and torch.equal(dist, ref[1]))
+            ref, ref1 = (idx.clone(), dist.clone()), (idx1.clone(), dist1.clone())
+        same = bool(torch.equal(idx, ref[0]) and torch.equal(dist, ref[1]) and torch.equal(idx1, ref1[0]) and torch.equal(dist1, ref1[1])
+                    and torch.equal(idx1b, ref1[0]) and torch.equal(dist1b, ref1[1]) and torch.equal(idx1, idx[:, :1]) and torch.equal(dist1, dist[:, :1]))
         us = timed(q, gal, qn, gn)
         res[name] = (round(us, 2), round(2.0 * P * G * D / us / 1e6, 1), 'same' if same else 'DIFFERENT')
-    lib.cvpce_match_set_core(0, 0)
-    print(f'{P} x {G} x {D}: ' + '  '.join(f'{k} {v[0]} us {v[1]} TF {v[2]}' for k, v in res.items()), flush=True)
+    lib.cvpce_match_set_core(0, 0, 0, 0)
+    bad = [k for k, v in res.items() if v[2] != 'same']
+    print(f'{P} x {G} x {D}: ' + '  '.join(f'{k} {v[0]}' for k, v in res.items()) + (f'  DIFFERENT: {bad}' if bad else '  (all identical)'), flush=True)
