@@ -649,7 +649,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
     if not args.no_workloads and rank == 0:
         # BASELINE configs[1] and configs[3] on this same box (a few hundred ms of GPU time): the driver only runs the default line
         # (taken BEFORE the CPU-heavy legs: the oracle's OpenMP threads keep spinning for a while and slow the launch path)
-        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False)
+        w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False, want_layers=True)
         workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
                      'match_stress_configs3': match_stress_cases(dev, 200, 3),
                      'embed_planted_boxes': embed_planted_boxes(dev, enc, images[0], ipg * dpi)}
@@ -819,7 +819,37 @@ def embed_planted_boxes(dev, enc, image, n_boxes, seed=7, reps=5):
 # ---------------------------------------------------------------------------------------------------------------------
 # workload: detector only (BASELINE configs[1])
 # ---------------------------------------------------------------------------------------------------------------------
-def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16', ids=None, windows=1, want_profile=False, collective=True):
+def detector_layers(layers, steps, graph_ms):
+    """`workloads.detector_configs1.layers`: the detector pass launch class by launch class (kernel + layer shape, launches of the step summed) --
+    algorithmic FLOPs and bytes (inputs + outputs + weights once), arithmetic intensity, which roof binds it (MFMA above the ridge of
+    2500 TFLOP/s / 8 TB/s = 312 FLOP/B, else HBM; 'latency' for the post-processing, which is neither) and the fraction of THAT roof
+    reached.  Times are HIP events around the EAGER launches of a profiled pass (the production pass replays a hipGraph): their sum is
+    given beside the graph-replayed pass time -- side branches that overlap in the graph are serial here."""
+    ridge = MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    out = []
+    for key, d in layers.items():
+        ms = d['ms'] / steps
+        fl, by = d['flops'] / steps, d['bytes'] / steps
+        ai = fl / by if by > 0 else 0.0
+        bound = 'latency' if fl == 0 and 'postprocess' in key else ('mfma' if ai >= ridge else 'hbm')
+        e = {'launch_class': key, 'launches': round(d['launches'] / steps, 1), 'us': round(ms * 1e3, 1), 'gflop': round(fl / 1e9, 2), 'mb': round(by / 1e6, 1),
+             'flop_per_byte': round(ai, 1), 'bound': bound}
+        if ms > 0 and bound == 'mfma':
+            e['tflops'] = round(fl / ms / 1e9, 1)
+            e['frac_of_roof'] = round(fl / ms / 1e9 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
+        elif ms > 0 and bound == 'hbm':
+            e['gbs'] = round(by / ms / 1e6, 1)
+            e['frac_of_roof'] = round(by / ms / 1e6 / HBM_PEAK_GBS, 4)
+        out.append(e)
+    out.sort(key=lambda e: -e['us'])
+    tot = sum(e['us'] for e in out)
+    return {'classes': out, 'sum_of_eager_launches_us': round(tot, 1), 'graph_replayed_pass_us': round(graph_ms * 1e3, 1),
+            'floor_us_at_the_roofs': round(sum((e['gflop'] / MFMA_BF16_DENSE_PEAK_TFLOPS * 1e-3 if e['bound'] == 'mfma' else e['mb'] / HBM_PEAK_GBS * 1e-3) * 1e6
+                                               for e in out if e['bound'] != 'latency'), 1),
+            'note': 'per launch class: algorithmic work, binding roof, achieved fraction of it; floor = every class at its roof, no overlap'}
+
+
+def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16', ids=None, windows=1, want_profile=False, collective=True, want_layers=False):
     """`ipg` shelf images through the GLN detector only (transform, ResNet-50 + FPN, Gaussian branch, heads, top-k / NMS), the
     graph-replayed schedule `GLNEngine.detect` runs in production.  -> dict of figures (+ the engine / model for the caller)."""
     from cvpce_amd import ops, synthetic
@@ -842,12 +872,15 @@ def detector_workload(dev, ipg, dpi, image_size, steps, warmup, precision='bf16'
            'algorithmic_gflop': round(gf, 1), 'tflops': round(gf / ms, 1), 'frac_of_mfma_peak': round(gf / ms / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
     if windows > 1:
         res['windows'] = window_stats(secs, steps)
-    if want_profile:
+    if want_profile or want_layers:
         ops.PROFILE = ops.ConvProfile()
         for _ in range(steps):
             step()
         res['_conv_summary'] = ops.PROFILE.summary()
+        layers = ops.PROFILE.summary_layers()
         ops.PROFILE = None
+        if want_layers:
+            res['layers'] = detector_layers(layers, steps, ms)
     res['_elapsed'] = elapsed
     return res
 

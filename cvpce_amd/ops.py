@@ -119,6 +119,23 @@ class ConvProfile:
     def __init__(self):
         self.records = []   # (variant, flops, start_event, end_event)
         self.byte_records = []   # HBM-bound launches: (kernel, algorithmic bytes, start_event, end_event)
+        self.layer_records = []  # detector launch classes: (kernel + layer shape, algorithmic FLOPs, algorithmic bytes, start_event, end_event)
+
+    def layer(self, key, flops, nbytes, e0, e1):
+        self.layer_records.append((key, float(flops), float(nbytes), e0, e1))
+
+    def summary_layers(self):
+        """per launch class (kernel, layer shape): launches, algorithmic FLOPs and bytes (inputs + outputs + weights once), milliseconds --
+        bench.py `workloads.detector_configs1.layers`."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, nbytes, e0, e1 in self.layer_records:
+            d = out.setdefault(key, {'launches': 0, 'flops': 0.0, 'bytes': 0.0, 'ms': 0.0})
+            d['launches'] += 1
+            d['flops'] += flops
+            d['bytes'] += nbytes
+            d['ms'] += e0.elapsed_time(e1)
+        return out
 
     @staticmethod
     def variant(pc, m):
@@ -210,6 +227,8 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
             e1.record()
             prof.records.append(('conv3x3_halo3_kernel' if pc.cout <= 128 else 'conv3x3_halo2_kernel',
                                  2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+            prof.layer(f"{'conv3x3_halo3' if pc.cout <= 128 else 'conv3x3_halo2'} {h}x{w} {pc.cin}->{pc.cout}" + (' +pool' if pool else ''),
+                       2.0 * n * ho * wo * pc.cout * 9 * pc.cin, _nbytes(x, out, pc.weight), e0, e1)
         return out
     # thin 3x3 layers (the Gaussian subnet's 64 -> 32 over an upsampled input, 32 -> 32, 32 -> 16, all on the 400 x 400 map): weights in
     # registers, input rows streamed through LDS (csrc/thin3x3.hip)
@@ -222,6 +241,8 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
             e1.record()
             prof.records.append(('thin3x3_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
             prof.byte_records.append(('thin3x3_kernel', _nbytes(x, out, pc.weight), e0, e1))
+            prof.layer(f'thin3x3 {ho}x{wo} {pc.cin}->{pc.cout}' + (' (2x upsampled input)' if in_up_shift else ''), 2.0 * n * ho * wo * pc.cout * 9 * pc.cin,
+                       _nbytes(x, out, pc.weight), e0, e1)
         return out
     # pointwise GEMM kernel: wins on the expansion convs (short K, 4x wider output: HBM-bound, 1.3-1.8x), loses on long K
     if (USE_CONV1X1 and not FORCE_GENERIC_CONV and pc.kh == 1 and pc.kw == 1 and pc.pad == 0 and cin % 64 == 0 and pc.k_pad == cin
@@ -232,6 +253,8 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
             prof.records.append(('conv1x1_kernel', 2.0 * n * ho * wo * pc.cout * pc.cin, e0, e1))
             # a strided 1x1 reads only the pixels it keeps; an upsampled residual (res_mode 2) is read at its stored size
             prof.byte_records.append(('conv1x1_kernel', n * ho * wo * cin * x.element_size() + _nbytes(out, residual, pc.weight), e0, e1))
+            prof.layer(f'conv1x1 {ho}x{wo} {pc.cin}->{pc.cout} s{pc.stride}' + (' +res' if residual is not None else ''), 2.0 * n * ho * wo * pc.cout * pc.cin,
+                       n * ho * wo * cin * x.element_size() + _nbytes(out, residual, pc.weight), e0, e1)
         return out
     T.conv2d_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
                   int(act), int(out_f32), int(in_up_shift), int(res_mode), int(pool), int(FORCE_GENERIC_CONV))   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
@@ -239,6 +262,8 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         e1.record()
         # algorithmic FLOPs: real (unpadded) channels, 2 FLOP per MAC
         prof.records.append((prof.variant(pc, n * ho * wo), 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, e0, e1))
+        prof.layer(f"{prof.variant(pc, n * ho * wo).split('<')[0]} {ho}x{wo} {pc.cin}->{pc.cout} k{pc.kh} s{pc.stride}" + (' f32 out' if out_f32 else ''),
+                   2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, _nbytes(x, out, residual, pc.weight), e0, e1)
     return out
 
 
@@ -280,6 +305,8 @@ def bottleneck(x, c1, c2, c3, residual):
     if prof is not None:
         e1.record()
         prof.records.append(('bneck_kernel', 2.0 * n * h * w * (cin * p + 9 * p * p + 4 * p * p), e0, e1))
+        prof.layer(f'bneck {h}x{w} {cin}->{p}->{4 * p}', 2.0 * n * h * w * (cin * p + 9 * p * p + 4 * p * p),
+                   _nbytes(x, out, c1.weight, c2.weight, c3.weight) + (0 if residual.data_ptr() == x.data_ptr() else _nbytes(residual)), e0, e1)
     return out
 
 
@@ -361,6 +388,7 @@ def gln_stem(x, ps):
     if prof is not None:
         e1.record()
         prof.records.append(('gln_stem_kernel', 2.0 * n * hc * wc * 64 * 147, e0, e1))
+        prof.layer(f'gln_stem {h}x{w} 3->64 k7 s2 +pool', 2.0 * n * hc * wc * 64 * 147, _nbytes(x, out), e0, e1)
     return out
 
 
@@ -396,6 +424,8 @@ def conv3x3_atlas(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None)
         e1.record()
         npix = float(mask.sum().item()) if mask_pixels is None else float(mask_pixels)
         prof.records.append(('conv3x3_halo2_kernel', 2.0 * npix * n * pc.cout * 9 * pc.cin, e0, e1))
+        prof.layer(f'conv3x3_halo2 atlas {pc.cin}->{pc.cout} (head tower)', 2.0 * npix * n * pc.cout * 9 * pc.cin,
+                   2 * npix * n * (pc.cin + pc.cout) * x.element_size() + _nbytes(pc.weight), e0, e1)
     return out
 
 
@@ -575,6 +605,7 @@ def gauss_tail(x, c4, c5, act):
         e1.record()
         prof.records.append(('gauss_tail_kernel', 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * (16 * 16 + 16), e0, e1))
         prof.byte_records.append(('gauss_tail_kernel', _nbytes(x, out), e0, e1))
+        prof.layer(f'gauss_tail {x.shape[1]}x{x.shape[2]} 16->16->1', 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * (16 * 16 + 16), _nbytes(x, out), e0, e1)
     return out
 
 
@@ -618,6 +649,7 @@ def gln_transform_batch(images, batch, sizes, mean, std):
     if prof is not None:
         e1.record()
         prof.byte_records.append(('gln_transform_batch_kernel', _nbytes(batch, *images), e0, e1))
+        prof.layer('gln_transform_batch', 0.0, _nbytes(batch, *images), e0, e1)
 
 
 MAX_CROPS_PER_LAUNCH = 65535
@@ -700,9 +732,16 @@ def detect_postprocess(logits, regs, grids, strides, base_anchors, image_hw, rat
         conf = torch.zeros((n,), dtype=torch.int32, device=dev)
     for t in list(logits) + list(regs):
         assert t.dtype == torch.float32 and t.is_contiguous()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     T.detect_postprocess(list(logits), list(regs), [int(g[0]) for g in grids], [int(g[1]) for g in grids], [int(s[0]) for s in strides],
                          [int(s[1]) for s in strides], base_anchors, image_hw, ratios, num_anchors, num_classes, topk, float(score_thresh),
                          float(nms_thresh), float(xform_clip), detections_per_img, float(conf_thresh), ws, boxes, scores, labels, count, conf)
+    if prof is not None:
+        e1.record()
+        prof.layer(f'detect_postprocess (top-k {topk}, NMS, dpi {detections_per_img}: 5 launches)', 0.0, _nbytes(*logits, *regs, boxes, scores, labels), e0, e1)
     return boxes, scores, labels, count, conf
 
 

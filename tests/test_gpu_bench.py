@@ -71,6 +71,11 @@ def test_pipeline_line_small(cuda):
         if not name.startswith('_'):
             assert e['algorithmic_gb_per_step'] > 0 and e['ms_per_step'] > 0 and 0 < e['frac_of_hbm_peak'] <= 1.0, (name, e)
     assert d['config']['collectives'] is None            # one rank, no process group
+    # round 5: the detector of BASELINE configs[1] launch class by launch class against the roof that binds each
+    ly = w['detector_configs1']['layers']
+    assert len(ly['classes']) >= 20 and ly['sum_of_eager_launches_us'] > 0 and 0 < ly['floor_us_at_the_roofs'] < ly['graph_replayed_pass_us']
+    assert {e['bound'] for e in ly['classes']} >= {'mfma', 'hbm', 'latency'}
+    assert all(0 < e['frac_of_roof'] <= 1.0 for e in ly['classes'] if e['bound'] != 'latency'), ly['classes']
 
 def test_detector_and_match_stress_lines(cuda):
     d = _run('--workload', 'detector', '--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--no-cpu-baseline')

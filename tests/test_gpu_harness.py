@@ -143,3 +143,9 @@ def test_evaluate_batch_equals_per_image(cuda):
     want = [float(ev.evaluate(im, p)) for im, p in zip(imgs, planos)]
     got = [float(v) for v in ev.evaluate_batch(imgs, planos)]
     assert got == want and any(0.0 < v < 1.0 for v in want), (got, want)
+    # the look-ahead iterator (round 5): the per-image calling pattern, pairs from a generator, windows cut at a size change and at
+    # `lookahead` -- every yielded verdict is the serial call's
+    for la in (1, 2, 4):
+        gen = ev.evaluate_iter(((im, p) for im, p in zip(imgs, planos)), lookahead=la)
+        assert [float(v) for v in gen] == want, la
+    assert list(ev.evaluate_iter(iter(()))) == []

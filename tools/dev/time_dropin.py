@@ -50,3 +50,12 @@ for src, what in ((imgs, 'host images'), (dimgs, 'device images')):
         res = ev.detect_and_classify_batch(src)
         torch.cuda.synchronize(); dt = time.time() - t
     print(f'detect_and_classify_batch ({what}): {len(imgs) / dt:.1f} images/s ({sum(len(b) for b, _ in res)} boxes)')
+# the look-ahead iterator over a stream of (image, planogram) pairs (PlanogramEvaluator.evaluate_iter): the per-image calling pattern with the
+# detector / embedder passes shared by up to `lookahead` consecutive images; planograms = each image's own detections (comparator included)
+planos = [{'boxes': b, 'labels': l} for b, l in res]
+for la in (1, 2, 4, 8):
+    for rep in range(3):
+        torch.cuda.synchronize(); t = time.time()
+        out = list(ev.evaluate_iter(zip(dimgs, planos), lookahead=la))
+        torch.cuda.synchronize(); dt = time.time() - t
+    print(f'evaluate_iter(lookahead={la}): {len(imgs) / dt:.1f} images/s (comparator included)')
