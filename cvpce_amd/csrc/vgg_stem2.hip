@@ -254,6 +254,10 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
             // pairs, all ones except on the tiles that touch the image border)
             const int y = ty * S2_T - 1 + py, x = tx * S2_T - 1 + px;
             const unsigned keep = ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) ? 0xFFFFFFFFu : 0u;
+#ifndef S2_WIDE_STORE
+            // eight 8-byte stores per lane and pixel tile (two-way bank conflicts: the 32 pixels of a half wave fall on 16 bank positions).  The
+            // conflict-free form below (-DS2_WIDE_STORE) was built and measured in round 5: 1-4 % SLOWER -- the stores are not what this phase
+            // waits on, the four extra v_permlane32_swap pairs are (profiles/r05_rejected_experiments.md)
             if (real) {
                 const int abase = (py * S2_P1 + px) * 128 + lh * 8;
                 const int aswz = (s2_swz0(px >> 1) ^ (py & 1)) << 4;
@@ -266,10 +270,30 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
                         for (int j = 0; j < 4; ++j) r[j] = relu_bits(acc[ct][4 * g + j]);
                         uint2 u = __builtin_bit_cast(uint2, f32x4_to_bf16x4(r));
                         if (border) { u.x &= keep; u.y &= keep; }
-                        // channels co = ct*32 + 8g + 4lh .. +3 = chunk ct*4 + g, bytes lh*8 .. +7
                         *reinterpret_cast<uint2*>(A1 + abase + (((ct * 4 + g) << 4) ^ aswz)) = u;
                     }
             }
+#else
+            // (-DS2_WIDE_STORE, measured and not adopted) A lane holds 4 channels (8 bytes) of each 16-byte chunk, its partner lane (l ^ 32) the
+            // other 4: one v_permlane32_swap pair per chunk pair hands lane lh the WHOLE chunk 2m + lh -- 4 stores of 16 bytes, 16 lanes of a
+            // quarter wave on 16 different 16-byte bank groups (conflict-free).
+            const int abase = (py * S2_P1 + px) * 128;
+            const int aswz = (s2_swz0(px >> 1) ^ (py & 1)) << 4;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 ra, rb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ra[j] = relu_bits(acc[ct][8 * m + j]); rb[j] = relu_bits(acc[ct][8 * m + 4 + j]); }
+                    uint2 ua = __builtin_bit_cast(uint2, f32x4_to_bf16x4(ra)), ub = __builtin_bit_cast(uint2, f32x4_to_bf16x4(rb));
+                    if (border) { ua.x &= keep; ua.y &= keep; ub.x &= keep; ub.y &= keep; }
+                    // channels co = ct*32 + 8g + 4lh .. +3 = bytes lh*8 .. +7 of chunk ct*4 + g; g = 2m (ua), 2m + 1 (ub)
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+                    if (real) *reinterpret_cast<u32x4*>(A1 + abase + (((ct * 4 + 2 * m + lh) << 4) ^ aswz)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+#endif
         }
         S2_STAMP(1)
         team_barrier(cnt_addr, bar_target, lane);

@@ -125,11 +125,21 @@ def _compare_detections(r, ref, min_frac=0.8):
     assert (gb[matched] - rb[arg[matched]]).abs().max() < 2e-3 * scale + 0.5
 
 
-def test_gln_intermediates_and_stage_exact(cuda, gln_model):
+@pytest.mark.parametrize('precision', ['fp16', 'bf16'])
+def test_gln_intermediates_and_stage_exact(cuda, gln_model, precision):
     """Two images of different shapes in one batch (ragged -> padded), all intermediate tensors
-    against the oracle, then K6-K8 re-run by the oracle on the GPU's own fp32 head outputs: exact."""
+    against the oracle, then K6-K8 re-run by the oracle on the GPU's own fp32 head outputs: exact.
+    Both storage modes of the detector: fp16 (the default) and the opt-in bf16, each against the CPU model of ITS rounding points."""
     from oracle import gln as og
     model, sd = gln_model
+    model.set_precision(precision)
+    try:
+        _gln_intermediates_and_stage_exact(cuda, model, sd, og)
+    finally:
+        model.set_precision('fp16')
+
+
+def _gln_intermediates_and_stage_exact(cuda, model, sd, og):
     imgs = [torch.rand(3, 480, 640, generator=torch.Generator().manual_seed(1)),
             torch.rand(3, 700, 500, generator=torch.Generator().manual_seed(2))]
     eng = model.engine()
@@ -149,14 +159,15 @@ def test_gln_intermediates_and_stage_exact(cuda, gln_model):
     assert l2rel(gauss.cpu(), rint['gaussians']) < 0.25     # ill-conditioned with random weights (sparse ReLU output)
     # (2) every stage against the CPU model of the SAME numerics, fed the GPU's own stage inputs: tight
     from oracle import bf16_model as bm
+    nm = bm.FP16 if model.precision == 'fp16' else bm.BF16
     c2, c3, c4, c5 = [nchw(t) for t in inter['c']]
     feats = [nchw(t) for t in inter['features']]
-    m_c = bm.body(nchw(inter['batch'])[:, :3], sd)
+    m_c = bm.body(nchw(inter['batch'])[:, :3], sd, nm=nm)
     assert l2rel(c2, m_c[0]) < 2e-3, l2rel(c2, m_c[0])     # stem + layer1 (10 convs, pool, 3 residual adds)
-    for got, want in zip(feats, bm.fpn(c3, c4, c5, sd)):
+    for got, want in zip(feats, bm.fpn(c3, c4, c5, sd, nm=nm)):
         assert l2rel(got, want) < 2e-3, l2rel(got, want)
-    assert l2rel(gauss.cpu(), bm.gaussian_branch(c2, feats[0], sd)) < 3e-2   # 8 layers, sparse output: see the golden test below
-    m_cls, m_reg = bm.heads(feats, sd)
+    assert l2rel(gauss.cpu(), bm.gaussian_branch(c2, feats[0], sd, nm=nm)) < 3e-2   # 8 layers, sparse output: see the golden test below
+    m_cls, m_reg = bm.heads(feats, sd, nm=nm)
     for got, want in zip(inter['cls'], m_cls):
         assert (got.view(2, -1).cpu() - want.view(2, -1)).abs().max() < 0.03 * want.std() + 5e-3
     for got, want in zip(inter['reg'], m_reg):
@@ -333,7 +344,7 @@ def test_head_atlas_equals_per_level(cuda, gln_model, hw):
     shapes, (h, w) = [], hw
     for _ in range(5):
         shapes.append((h, w)); h, w = (h + 1) // 2, (w + 1) // 2
-    feats = [torch.randn(2, h, w, 256, generator=g).to(torch.bfloat16).to(cuda) for h, w in shapes]
+    feats = [torch.randn(2, h, w, 256, generator=g).to(eng.dtype).to(cuda) for h, w in shapes]      # (the engine's storage type: fp16 by default)
     hc, wc, offs = eng.atlas_layout(shapes)
     occ = torch.zeros(hc + 2, wc + 2, dtype=torch.int32)
     for (h, w), (oy, ox) in zip(shapes, offs):          # levels (grown by the 1-pixel halo) never overlap another level
