@@ -8,9 +8,12 @@ set -e
 tag=$1
 R=$PWD; O=$R/gpurun_out; B=$R/bench.py
 cd /tmp; export TMPDIR=/tmp
+if [ -z "$SKIP_STATS" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $B --steps 5 --warmup 2 > $O/prof_$tag.log 2>&1
 echo "stats pass done"
-Q="--steps 1 --warmup 1 --windows 1 --no-roofline --no-cpu-baseline --no-parity --no-h2d --no-peaks --no-workloads --no-precision-leg"
+fi
+# (the counter passes end with ONE headline step: every side leg off, so that "the last pipeline pass" of the trace is that step)
+Q="--steps 1 --warmup 1 --windows 1 --no-roofline --no-cpu-baseline --no-parity --no-h2d --no-peaks --no-workloads --no-precision-leg --no-coheadlines"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_$tag/fetch -- python3 $B $Q > /dev/null 2>&1
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_$tag/write -- python3 $B $Q > /dev/null 2>&1
@@ -19,7 +22,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE
 echo "sq pass done"
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_$tag/tcc -- python3 $B $Q > /dev/null 2>&1
 echo "tcc pass done"
-grep -o '{"metric.*' $O/prof_$tag.log | tail -1 > $O/prof_$tag.json
+[ -z "$SKIP_STATS" ] && grep -o '{"metric.*' $O/prof_$tag.log | tail -1 > $O/prof_$tag.json
 # the traces are large: keep only what the summary needs (gpurun merges at most 64 MiB back)
 find $O/prof_$tag -name '*_kernel_trace.csv' -size +40M -delete
 du -sh $O/prof_$tag $O/pmc_$tag
