@@ -684,9 +684,9 @@ def run_pipeline(args, rank, local_rank, world, dev):
                                       ('frac_oracle_boxes_iou90', 'ap50_area_vs_oracle', 'paired_box_diff_px_mean')}
                                  for p_, e_ in fs['by_precision'].items()}}
         parity['sample'] = ('4 structured shelf images through the whole HIP pipeline vs the whole fp32 CPU oracle; top level = the detector '
-                            f'precision of this run ({args.detector_precision}), by_precision = both detector modes (bf16 default, fp16 accuracy mode); '
+                            f'precision of this run ({args.detector_precision}: fp16 is the product default), by_precision = both detector modes (fp16 default, bf16 opt-in); '
                             '64 paired detections + 64 ground-truth crops vs a 256-product gallery; full-size figures (32 images, '
-                            'G = 1000 / 3200): profiles/r03_accuracy.json')
+                            'G = 1000 / 3200): profiles/r05_accuracy.json')
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
