@@ -21,7 +21,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
 
 #ifndef CVPCE_DBG
-#define CVPCE_DBG 0          // compile-time ablations (tools/ablate.sh): 4 no patch DMA after the first two sub-chunks, 8 no weight
+#define CVPCE_DBG 0          // compile-time ablations (tools/ablate.sh): 64 no hand-off wait / barrier, 4 no patch DMA after the first two sub-chunks, 8 no weight
 #endif                       // loads in the loop, 16 no stores (runtime-false predicate), 32 no fragment reads; timing only; 2 plain tile order
 #define G3_TH 16
 #define G3_TW 32
@@ -67,8 +67,13 @@ extern "C" int cvpce_debug_halo3_stamps(unsigned long long* host_out) {
 #define G3_STAMP_STEP()
 #endif
 
-template <typename E, bool POOL, bool LIST>
+// THIN (round 5): the RetinaNet head's OUTPUT convs (256 -> 9 class logits, 256 -> 36 box regressions; fp32 outputs, no activation): Cout is
+// any number <= 128, the output is [N][H][W][Cout] float, and a wave whose 32-cout group holds no real cout only takes part in the patch
+// DMA and the barriers (no weight loads, fragment reads or MFMAs).  As register-staged implicit GEMMs these two layers cost 72 + 60 us per
+// 4 images for ~10 us of traffic each (36 K-steps of gathers per 128-pixel tile); here the patch of a 16 x 32 tile is fetched once per chunk.
+template <typename E, bool POOL, bool LIST, bool THIN = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
+    static_assert(!THIN || (!POOL && !LIST), "thin-output form: plain launches only");
 #if CVPCE_DBG & 128
     unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wid >> 1, wp = wid & 1;
     const int l16 = lane & 15, lq = lane >> 4;
+    const bool active = THIN ? (wc * 32 < a.Cout) : true;       // (THIN: this wave's cout group holds a real cout; wave-uniform)
 
     const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
@@ -198,7 +204,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int co = ct * TC + wc * 32 + 8 * lq + 4 * mt;
-            b[mt] = (a.bias && co < a.Cout) ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (THIN) {                      // Cout is not a multiple of 4: element by element
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[mt][j] = (a.bias && co + j < a.Cout) ? a.bias[co + j] : 0.f;
+            } else {
+                b[mt] = (a.bias && co < a.Cout) ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     f32x4 acc[2][NB];
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // ROW STREAMING (see conv3x3_halo2.hip): step T = sub-chunk * 3 + kw of a body (0..5) holds the weights of the three
     // taps (kh, kw) of its 32 channels, reads each of the 18 patch rows once and issues up to 6 MFMAs on it.
 #define G3_LOAD_A(T, SBASE)                                                                                    \
-    if constexpr (!(CVPCE_DBG & 8)) {                                                                          \
+    if constexpr (!(CVPCE_DBG & 8)) if (active) {                                                              \
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) {                                              \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff1, (SBASE) + (((((T) % 3) * 2 + (T) / 3) * 3 + kh_) * 2 + mt_) * 1024, 0); \
@@ -228,11 +239,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
 #define G3_SET_E(T, BUFB) { e0 = c3[(T) % 3] + (BUFB); }
     // read patch row P of step T into ring slot (P + 2 T) & 3 (a step has 18 rows, 18 = 2 mod 4)
 #define G3_READ(T, P)                                                                                          \
-    if constexpr (!(CVPCE_DBG & 32))                                                                           \
+    if constexpr (!(CVPCE_DBG & 32)) if (active)                                                               \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[((P) + 2 * (T)) & 3]) : "v"(e0), "n"(((P) * G3_PW + (T) % 3) * 64));
     // the MFMAs of patch row P: output rows P (kh = 0), P-1 (kh = 1), P-2 (kh = 2) where they exist
 #define G3_ROW(T, P)                                                                                           \
-    {                                                                                                          \
+    if (active) {                                                                                              \
         if constexpr (!(CVPCE_DBG & 32)) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[((P) + 2 * (T)) & 3]));  \
         _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                    \
             if ((P) - kh_ >= 0 && (P) - kh_ < NB) {                                                            \
@@ -251,8 +262,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
     // the pieces two steps instead of one before a weight wait can stall on them -- no gain, conv2_1 0.70 -> 0.72 ms.)
 #define G3_HANDOFF()                                                                                           \
     {                                                                                                          \
-        { G3_TIC() asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); G3_TOC(1) }                                \
-        { G3_TIC() __builtin_amdgcn_s_barrier(); G3_TOC(2) }                                                   \
+        { G3_TIC() if (!(CVPCE_DBG & 64)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); G3_TOC(1) }         \
+        { G3_TIC() if (!(CVPCE_DBG & 64)) __builtin_amdgcn_s_barrier(); G3_TOC(2) }     /* (64: timing-only ablation, no hand-off wait / barrier) */ \
         issue_next_patch();                                                                                    \
     }
     // LIST launches compute only the first `rows_` (4 | 8 | 12 | 16) output rows of a tile: see G2_ROWS_AND_TAIL in conv3x3_halo2.hip
@@ -337,7 +348,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo3_kernel(Halo3Args a) {
             f32x4 nbias[2];                      // bias of the NEXT tile's couts: lands while this tile is stored
             load_bias(n_ct, nbias);
             const int col = g3_col(lp);
-            if (POOL) {
+            if constexpr (THIN) {
+                // fp32 outputs, [pixel][Cout] with any Cout: this lane's (up to) 8 couts of its pixel, 16 bytes at a time where Cout % 4 == 0
+                float* outf = reinterpret_cast<float*>(a.out);
+                const int ox = tx * G3_TW + 16 * wp + col;
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) {
+                    const int oy = ty * G3_TH + nt;
+                    if (active && oy < a.H && ox < a.W) {
+                        float* po = outf + ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const int co = wc * 32 + 8 * lq + 4 * mt;
+                            if ((a.Cout & 3) == 0) {
+                                if (co < a.Cout) *reinterpret_cast<f32x4*>(po + co) = acc[mt][nt];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (co + j < a.Cout) po[co + j] = acc[mt][nt][j];
+                            }
+                        }
+                    }
+                }
+            } else if (POOL) {
                 // rows 2i, 2i+1 are blocks 2i, 2i+1 of the same lane; columns 2k, 2k+1 are lanes A[k], B[k] with
                 // A = {0-3,12-15}, B = {4-11}: lane A[k] takes its right neighbour by a row rotate (+4 for lanes 0-3,
                 // -4 for lanes 12-15; bank masks 1 and 8)
@@ -473,6 +506,39 @@ static int halo3_dispatch(const void* in, const void* wgt, const float* bias, vo
         if constexpr (!E::kF16) return fuse_pool2 ? launch_halo3<E, true, true>(a, s) : launch_halo3<E, false, true>(a, s);
     }
     return fuse_pool2 ? launch_halo3<E, true>(a, s) : launch_halo3<E, false>(a, s);
+}
+
+// the thin-output form: fp32 [N][H][W][Cout] outputs, Cout <= 128 and not necessarily a multiple of 8, no activation
+template <typename E>
+static int halo3_thin_dispatch(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W, int Cin, int Cout,
+                               int K_pad, int Cout_pad, void* stream) {
+    if (N <= 0) return CVPCE_OK;
+    if (!in || !wgt || !out) return CVPCE_ERR_ARG;
+    if (H <= 0 || W <= 0 || Cin % 64 != 0 || Cin <= 0 || Cout <= 0 || Cout > 128) return CVPCE_ERR_ARG;
+    if (K_pad != 9 * Cin || Cout_pad % 256 != 0 || Cout_pad < Cout) return CVPCE_ERR_ARG;
+    if ((long long)N * H * W * Cin * 2 >= (1LL << 32) || (long long)N * H * W * Cout >= (1LL << 31)) return CVPCE_ERR_ARG;
+    if ((long long)Cout_pad * K_pad * 2 >= (1LL << 31)) return CVPCE_ERR_ARG;
+    Halo3Args a;
+    a.in = (const bf16_t*)in; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out);
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K_pad = K_pad; a.relu = 0; a.cgroups = Cout_pad / 32;
+    a.tiles_x = (W + G3_TW - 1) / G3_TW; a.tiles_y = (H + G3_TH - 1) / G3_TH; a.ptiles = N * a.tiles_x * a.tiles_y;
+    a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+    a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
+    a.ctiles = 1; a.ntiles = a.ptiles;
+    a.list = nullptr; a.list_count = nullptr;
+    if ((long long)a.ptiles * (Cin / 64) >= (1LL << 29)) return CVPCE_ERR_ARG;
+    if (!cvpce_smem_attr_done<conv3x3_halo3_kernel<E, false, false, true>>((const void*)conv3x3_halo3_kernel<E, false, false, true>, 3 * G3_A_BYTES)) return CVPCE_ERR_LAUNCH;
+    const int grid = a.ntiles < g_cvpce_persistent_wgs ? a.ntiles : g_cvpce_persistent_wgs;
+    hipLaunchKernelGGL((conv3x3_halo3_kernel<E, false, false, true>), dim3(grid), dim3(512), 3 * G3_A_BYTES, (hipStream_t)stream, a);
+    return cvpce_check_launch();
+}
+extern "C" int cvpce_conv3x3_halo_thin_out(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W,
+                                           int Cin, int Cout, int K_pad, int Cout_pad, void* stream) {
+    return halo3_thin_dispatch<ElemBF16>(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, stream);
+}
+extern "C" int cvpce_conv3x3_halo_thin_out_f16(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W,
+                                               int Cin, int Cout, int K_pad, int Cout_pad, void* stream) {
+    return halo3_thin_dispatch<ElemF16>(in, wgt, bias, out, N, H, W, Cin, Cout, K_pad, Cout_pad, stream);
 }
 
 extern "C" int cvpce_conv3x3_halo_wide(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W,

@@ -220,6 +220,17 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    # the RetinaNet head's output convs (256 -> 9 | 36, fp32 out, no activation): the 16 x 32-pixel halo-patch kernel with only the waves
+    # that hold a real cout computing (csrc/conv3x3_halo3.hip THIN) -- 72 + 60 us per 4 images as register-staged implicit GEMMs
+    if (USE_HALO_THIN_OUT and not FORCE_GENERIC_CONV and out_f32 and act == 0 and residual is None and not in_up_shift and not pool
+            and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and pc.cin_pad % 64 == 0 and cin == pc.cin_pad and pc.cout <= 64
+            and min(h, w) >= 48 and n * h * w * pc.cin_pad * 2 < 2 ** 32):
+        T.conv3x3_halo_thin_out(x, pc.weight_halo, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad)
+        if prof is not None:
+            e1.record()
+            prof.records.append(('conv3x3_halo3_kernel', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, e0, e1))
+            prof.layer(f'conv3x3_halo3 thin out {ho}x{wo} {pc.cin}->{pc.cout} f32 out', 2.0 * n * ho * wo * pc.cout * 9 * pc.cin, _nbytes(x, out, pc.weight), e0, e1)
+        return out
     if halo:
         # (Cout <= 128 is forwarded to the wide-tile kernel, conv3x3_halo3.hip, inside the library)
         T.conv3x3_halo(x, pc.weight_halo, pc.bias, out, pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool))
@@ -267,6 +278,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     return out
 
 
+USE_HALO_THIN_OUT = _os.environ.get('CVPCE_HALO_THIN_OUT', '1') != '0'   # A/B switch: the head's output convs through the thin-output form of the wide halo kernel
 USE_THIN_3X3 = _os.environ.get('CVPCE_THIN_3X3', '1') != '0'   # A/B switch: the thin 3x3 layers through csrc/thin3x3.hip
 USE_FUSED_BOTTLENECK = _os.environ.get('CVPCE_FUSED_BOTTLENECK', '1') != '0'   # A/B switch: stride-1 ResNet bottlenecks (P <= 256) in one launch (csrc/bneck.hip)
 

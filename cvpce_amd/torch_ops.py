@@ -77,6 +77,15 @@ def _conv3x3_halo(x, weight, bias, out, cout, k_pad, cout_pad, relu, pool):
     check(fn(_p(x), _p(weight), _p(bias), _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, pool, _stream()), 'cvpce_conv3x3_halo')
 
 
+@_op('conv3x3_halo_thin_out(Tensor x, Tensor weight, Tensor? bias, Tensor(a!) out, int cout, int k_pad, int cout_pad) -> ()')
+def _conv3x3_halo_thin_out(x, weight, bias, out, cout, k_pad, cout_pad):
+    n, h, w, cin = x.shape
+    if out.dtype != torch.float32:
+        raise RuntimeError('cvpce_conv3x3_halo_thin_out: the output is float32')
+    fn = _by_dtype(x, 'cvpce_conv3x3_halo_thin_out', 'cvpce_conv3x3_halo_thin_out_f16', weight)
+    check(fn(_p(x), _p(weight), _p(bias), _p(out), n, h, w, cin, cout, k_pad, cout_pad, _stream()), 'cvpce_conv3x3_halo_thin_out')
+
+
 @_op('conv3x3_halo_mac(Tensor x, Tensor weight, Tensor? bias, Tensor(a!)? out, Tensor(b!) mac, int mac_off, int cout, int k_pad, '
      'int cout_pad, int pool) -> ()')
 def _conv3x3_halo_mac(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad, pool):

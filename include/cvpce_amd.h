@@ -293,6 +293,14 @@ int cvpce_match_topk_state(const void* queries, const void* gallery, const float
  * (mg = 1 exists for nq <= 4); one_launch = 0 keeps cvpce_match_topk_state on the two-launch form. */
 int cvpce_match_set_core(int core, int nq, int mg, int one_launch);
 
+/* 3x3 / stride 1 / pad 1 convolution with FEW, arbitrarily many output channels and fp32 output, no activation: torchvision
+ * RetinaNetHead's `cls_logits` (256 -> A * K = 9) and `bbox_reg` (256 -> 4 A = 36) output convs, reached from
+ * cvpce/models/proposals.py:162-168.  in [N][H][W][Cin] (Cin % 64 == 0), wgt in the halo weight layout (Cout_pad % 256 == 0, rows
+ * beyond Cout zero), out [N][H][W][Cout] float, 1 <= Cout <= 128.  The 16 x 32-pixel halo-patch kernel of cvpce_conv3x3_halo_wide with
+ * only the waves that hold a real cout computing. */
+int cvpce_conv3x3_halo_thin_out(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W,
+                                int Cin, int Cout, int K_pad, int Cout_pad, void* stream);
+
 /* cvpce_conv3x3_halo_list's companion for a layer's STRIP list (Cout > 128 only): three listed tiles of which only the first 4
  * output rows are not constant are computed as ONE tile -- patch rows 6 s .. 6 s + 5 and accumulator rows 4 s .. 4 s + 3 belong to
  * strip s, all three share every weight fragment.  Same operands as cvpce_conv3x3_halo_list; writes the strips' rows into the same
@@ -312,6 +320,8 @@ int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const float* bias, co
                           int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
                           int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
+int cvpce_conv3x3_halo_thin_out_f16(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W,
+                                    int Cin, int Cout, int K_pad, int Cout_pad, void* stream);
 int cvpce_conv1x1_nhwc_f16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H,
                            int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad, int relu,
                            int res_mode, int Hr, int Wr, void* stream);

@@ -707,6 +707,39 @@ def test_conv3x3_halo_parity(cuda, n, cin, h, w, cout, pool):
         assert rel_err(nchw(y), ref) < 1e-2
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,cin,h,w,cout', [(2, 256, 100, 151, 9), (2, 256, 100, 151, 36), (1, 64, 50, 77, 9), (3, 128, 48, 48, 36), (1, 256, 64, 64, 1)])
+def test_conv3x3_thin_out_parity(cuda, dtype, n, cin, h, w, cout):
+    """The RetinaNet head's output convs (cls_logits 256 -> 9, bbox_reg 256 -> 36: fp32 out, no activation; reached from
+    cvpce/models/proposals.py:162-168) through the thin-output form of the wide halo kernel (round 5) against the register-staged implicit
+    GEMM they ran on before and against F.conv2d on the same rounded operands: ragged tiles in both dimensions, a Cout that is not a
+    multiple of 4 (scalar stores, element-wise bias), Cout = 1, both storage types of the detector."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, h, w, cin, generator=g).to(dtype)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, 1, 1, device=cuda, dtype=dtype)
+    xin = x.to(cuda)
+    ops.PROFILE = ops.ConvProfile()
+    try:
+        y = ops.conv2d(xin, pc, out_f32=True)
+        assert ops.PROFILE.layer_records[-1][0].startswith('conv3x3_halo3 thin out')          # the new path did run
+        ops.USE_HALO_THIN_OUT = False
+        y2 = ops.conv2d(xin, pc, out_f32=True)
+        assert not ops.PROFILE.layer_records[-1][0].startswith('conv3x3_halo3 thin out')
+    finally:
+        ops.USE_HALO_THIN_OUT = True
+        ops.PROFILE = None
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float32 and y.shape == y2.shape == (n, h, w, cout)
+    assert (y - y2).abs().max() <= 2e-5 * y2.abs().max() + 1e-6                   # the same products, another summation order
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wgt.to(dtype).float(), bias, padding=1)
+    assert rel_err(nchw(y), ref) < 1e-4
+    with pytest.raises(RuntimeError):
+        torch.ops.cvpce_amd.conv3x3_halo_thin_out(xin, pc.weight_halo, pc.bias, torch.empty((n, h, w, 200), dtype=torch.float32, device=cuda), 200, pc.k_pad, pc.cout_pad)
+
+
 @pytest.mark.parametrize('n,use_map', [(3, False), (3, True), (90, True), (50, False)])
 def test_conv3x3_atlas_masked(cuda, n, use_map):
     """cvpce_conv3x3_halo_masked: two maps packed side by side with a one-pixel zero gap == the conv applied to each map
