@@ -355,6 +355,9 @@ __global__ __launch_bounds__(256, TQ == 64 ? 3 : 2) void match_kernel(MatchArgs 
 typedef __attribute__((address_space(3))) void lds_void_m;
 typedef __attribute__((address_space(3))) char lds_char_m;
 #define MB_ROWB 128                        // bytes of one row of a K-stage (64 bf16)
+#ifndef MB_ABL
+#define MB_ABL 0
+#endif
 
 // MG = gallery fragments (32 rows) per wave: the tile is TG = 128 MG gallery rows (MG = 2: the throughput form; MG = 1: twice the workgroups
 // for launches that would otherwise leave most CUs without a tile -- a few hundred queries, where the time is the per-CU operand intake)
@@ -504,8 +507,12 @@ __global__ __launch_bounds__(512, 1) void match_big_kernel(MatchArgs a) {
         const int nb = (kt + 1) & 1;
         // stage kt has landed for this wave (its only loads in flight), and -- behind the barrier -- for every wave; every wave has
         // also finished its fragment reads of stage kt - 1 (lgkmcnt(0) above), whose buffer the next DMA overwrites
+#if !(MB_ABL & 1)           /* timing-only ablations (tools/dev/build_variant.sh match.hip abl -DMB_ABL=..): 1 no wait for the stage's DMA, 2 no barrier */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if !(MB_ABL & 2)
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         MB_READ(0, 0, soff)
         __builtin_amdgcn_sched_barrier(0);
