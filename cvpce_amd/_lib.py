@@ -57,6 +57,7 @@ SIGNATURES = {
     'cvpce_embed_worklists': (c_int, [_ip, c_int, c_int, ctypes.c_uint, _vp, c_int, _vp, c_longlong, _ip, _ip, _vp]),
     'cvpce_mac_init': (c_int, [_fp, c_int, c_int, c_int, c_int, _fp, _fp, c_int, c_int, _ip, _vp]),
     'cvpce_vgg_stem_fused_list': (c_int, [_vp, c_int, _vp, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp, _ip, _vp]),
+    'cvpce_bottleneck_fused_fm': (c_int, [_vp, _vp, _vp, _fp, _vp, _fp, _vp, _fp, _vp] + [c_int] * 5 + [_vp]),
     'cvpce_conv3x3_halo_thin_out': (c_int, [_vp, _vp, _fp, _fp] + [c_int] * 7 + [_vp]),
     'cvpce_conv3x3_halo_list': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 9 + [_vp, _ip, _vp]),
     'cvpce_conv3x3_halo_strips': (c_int, [_vp, _vp, _fp, _vp, _fp, c_int, c_int] + [c_int] * 9 + [_vp, _ip, _vp]),
@@ -79,7 +80,7 @@ SIGNATURES = {
 for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16'),
                      ('cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16'), ('cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16'),
                      ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_thin_out', 'cvpce_conv3x3_halo_thin_out_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
-                     ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'),
+                     ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'), ('cvpce_bottleneck_fused_fm', 'cvpce_bottleneck_fused_fm_f16'),
                      ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'), ('cvpce_gauss_tail_bf16', 'cvpce_gauss_tail_f16'), ('cvpce_conv3x3_thin_bf16', 'cvpce_conv3x3_thin_f16'),
                      ('cvpce_gln_transform', 'cvpce_gln_transform_f16'), ('cvpce_gln_transform_batch', 'cvpce_gln_transform_batch_f16')):
     SIGNATURES[_twin] = SIGNATURES[_base]

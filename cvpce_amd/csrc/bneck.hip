@@ -47,7 +47,12 @@ struct BneckArgs {
 template <int RB>
 __device__ __forceinline__ unsigned lds_swz(unsigned px) { return RB == 128 ? ((px >> 1) & 7u) : (px & 15u); }
 
-template <typename E, int P>
+// FM (round 5): the three weight tensors are FRAGMENT-MAJOR -- every MFMA weight fragment this kernel loads is one contiguous KiB, lane L's 16
+// bytes at byte 16 L (layouts: include/cvpce_amd.h cvpce_bottleneck_fused_fm; writer: cvpce_amd/ops.py pack_bottleneck_weights).  From the
+// row-major [Cout][K] tensors a fragment is 16 rows x 64 bytes, no two neighbouring lanes share a 64-byte block, and the texture addresser
+// takes such a load one lane per clock (~61 instead of 16 clocks): 94 of the 138 loads a wave issues per tile are weight fragments, and with
+// eight waves on one addresser that was most of a tile's 24 us.
+template <typename E, int P, bool FM>
 __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
     constexpr int RB = 2 * P;                      // bytes per LDS pixel row (mid1 and mid2 alike)
     constexpr int CB1 = P / 16;                    // 16-cout blocks of mid1
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
         // work items (K-step ks, sub-group sg) in order; the weight loads of item i+1 are issued before the MFMAs of item i
 #define BN_LOAD_A(SLOT, KS, SG)                                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                       \
-            A[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w1, woff[4 * (SG) + i_] + (unsigned)((KS) * 64), 0, 0));
+            A[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w1, FM ? (unsigned)((((KS) * CB1 + 4 * (SG) + i_) * 64 + lane) * 16) : woff[4 * (SG) + i_] + (unsigned)((KS) * 64), 0, 0));
 #define BN_LOAD_B(SLOT, KS)                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                       \
             B[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xin[i_] ? xoff[i_] + (unsigned)((KS) * 64) : 0xFFFFFFF0u, 0, 0));
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
             _Pragma("unroll") for (int kh_ = 0; kh_ < 3; ++kh_)                                                \
                 _Pragma("unroll") for (int h_ = 0; h_ < NCB; ++h_)                                             \
                     A2[SLOT][kh_][h_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(       \
-                        srd_w2, w2off[h_] + (unsigned)((((c64_ * 3 + kh_) * 3 + kw_) * 64 + hf_ * 32) * 2), 0, 0)); \
+                        srd_w2, FM ? (unsigned)((((((cg * ((P / 64) * 6) + (S)) * 3 + kh_) * NCB + h_) * 64) + lane) * 16)   \
+                                   : w2off[h_] + (unsigned)((((c64_ * 3 + kh_) * 3 + kw_) * 64 + hf_ * 32) * 2), 0, 0)); \
         }
         constexpr int NS = (P / 64) * 6;
         BN_LOAD_A2(0, 0)
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
         bf16x8 A3[2][2];
 #define BN_LOAD_A3(SLOT, KS)                                                                                   \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                       \
-            A3[SLOT][h_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w3, w3off[h_] + (unsigned)((KS) * 64), 0, 0));
+            A3[SLOT][h_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w3, FM ? (unsigned)(((((pass * 8 + wid) * (P / 32) + (KS)) * 2 + h_) * 64 + lane) * 16) : w3off[h_] + (unsigned)((KS) * 64), 0, 0));
         constexpr int NK3 = P / 32;
         BN_LOAD_A3(0, 0)
 #pragma unroll
@@ -300,15 +306,15 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
     }
 }
 
-template <typename E, int P>
+template <typename E, int P, bool FM>
 int launch_bneck(const BneckArgs& a, hipStream_t stream) {
     const int smem = BN_M1_PIX * 2 * P;
-    if (!cvpce_smem_attr_done<bneck_kernel<E, P>>((const void*)bneck_kernel<E, P>, smem)) return CVPCE_ERR_LAUNCH;
-    hipLaunchKernelGGL((bneck_kernel<E, P>), dim3((unsigned)(a.N * a.tiles_x * a.tiles_y)), dim3(512), smem, stream, a);
+    if (!cvpce_smem_attr_done<bneck_kernel<E, P, FM>>((const void*)bneck_kernel<E, P, FM>, smem)) return CVPCE_ERR_LAUNCH;
+    hipLaunchKernelGGL((bneck_kernel<E, P, FM>), dim3((unsigned)(a.N * a.tiles_x * a.tiles_y)), dim3(512), smem, stream, a);
     return cvpce_check_launch();
 }
 
-template <typename E>
+template <typename E, bool FM = false>
 int bneck_dispatch(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
                    const float* b3, void* out, int N, int H, int W, int Cin, int P, int k1_pad, int k2_pad, int k3_pad, int c1_pad,
                    int c2_pad, int c3_pad, void* stream) {
@@ -326,14 +332,20 @@ int bneck_dispatch(const void* x, const void* res, const void* w1, const float* 
     if ((long long)N * a.tiles_x * a.tiles_y >= (1LL << 31)) return CVPCE_ERR_ARG;
     a.x_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.res_bytes = (unsigned)((long long)N * H * W * 4 * P * 2);
-    a.w1_bytes = (unsigned)((long long)c1_pad * k1_pad * 2);
-    a.w2_bytes = (unsigned)((long long)c2_pad * k2_pad * 2);
-    a.w3_bytes = (unsigned)((long long)c3_pad * k3_pad * 2);
+    if (FM) {         // fragment-major tensors hold exactly the P x Cin, P x 9P and 4P x P weights (no padding rows / columns)
+        a.w1_bytes = (unsigned)((long long)P * Cin * 2);
+        a.w2_bytes = (unsigned)((long long)P * 9 * P * 2);
+        a.w3_bytes = (unsigned)((long long)4 * P * P * 2);
+    } else {
+        a.w1_bytes = (unsigned)((long long)c1_pad * k1_pad * 2);
+        a.w2_bytes = (unsigned)((long long)c2_pad * k2_pad * 2);
+        a.w3_bytes = (unsigned)((long long)c3_pad * k3_pad * 2);
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (P) {
-        case 64: return launch_bneck<E, 64>(a, s);
-        case 128: return launch_bneck<E, 128>(a, s);
-        default: return launch_bneck<E, 256>(a, s);
+        case 64: return launch_bneck<E, 64, FM>(a, s);
+        case 128: return launch_bneck<E, 128, FM>(a, s);
+        default: return launch_bneck<E, 256, FM>(a, s);
     }
 }
 
@@ -343,6 +355,14 @@ extern "C" int cvpce_bottleneck_fused(const void* x, const void* res, const void
                                       const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, int k1_pad,
                                       int k2_pad, int k3_pad, int c1_pad, int c2_pad, int c3_pad, void* stream) {
     return bneck_dispatch<ElemBF16>(x, res, w1, b1, w2, b2, w3, b3, out, N, H, W, Cin, P, k1_pad, k2_pad, k3_pad, c1_pad, c2_pad, c3_pad, stream);
+}
+extern "C" int cvpce_bottleneck_fused_fm(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
+                                         const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, void* stream) {
+    return bneck_dispatch<ElemBF16, true>(x, res, w1, b1, w2, b2, w3, b3, out, N, H, W, Cin, P, Cin, 9 * P, P, P, P, 4 * P, stream);
+}
+extern "C" int cvpce_bottleneck_fused_fm_f16(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
+                                             const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, void* stream) {
+    return bneck_dispatch<ElemF16, true>(x, res, w1, b1, w2, b2, w3, b3, out, N, H, W, Cin, P, Cin, 9 * P, P, P, P, 4 * P, stream);
 }
 extern "C" int cvpce_bottleneck_fused_f16(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
                                           const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, int k1_pad,

@@ -300,6 +300,54 @@ def can_fuse_bottleneck(x, c1, c2, c3, residual):
             and n * h * w * max(cin, 4 * p) * 2 < 2 ** 32)
 
 
+BNECK_FRAGMENT_MAJOR = _os.environ.get('CVPCE_BNECK_FM', '1') != '0'   # A/B switch: the fused bottleneck reads fragment-major weights (round 5)
+
+
+def pack_bottleneck_weights(c1, c2, c3):
+    """The three convs of a bottleneck in the FRAGMENT-MAJOR layouts of cvpce_bottleneck_fused_fm (include/cvpce_amd.h): every MFMA weight
+    fragment csrc/bneck.hip loads becomes one contiguous KiB, lane L = 16 lq + l16 at byte 16 L, 8 consecutive k per lane.
+      w1f [Cin/32 K-steps][P/16 cout blocks b][lane][8]:  cout = 32 (b >> 1) + 8 (l16 >> 2) + (l16 & 3) + 4 (b & 1),  k = 32 ks + 8 lq + e
+      w2f [P/CW cout groups][6 P/64 steps s = (c64, kw, half)][kh][CW/16 blocks h][lane][8]:  cout = CW cg + (CW == 32 ? 8 (l16 >> 2) + (l16 & 3) + 4 h : l16),
+           k = ((3 c64 + kh) 3 + kw) 64 + 32 half + 8 lq + e   (CW = 16 at P = 64, else 32; K chunk-major as in the packed conv weight)
+      w3f [4P/32 cout groups g][P/32 K-steps][2 blocks h][lane][8]:  cout = 32 g + 8 (l16 >> 2) + (l16 & 3) + 4 h,  k = 32 ks + 8 lq + e
+    -> (w1f, w2f, w3f) flat tensors of the convs' storage type on their device; cached on c1."""
+    cached = c1.__dict__.get('_bneck_fm')
+    if cached is not None and cached[0] is c2 and cached[1] is c3:
+        return cached[2]
+    p, cin = c1.cout, c1.cin_pad
+    dev = c1.weight.device
+    l16, lq, e = torch.arange(16), torch.arange(4), torch.arange(8)
+    pair = 8 * (l16 >> 2) + (l16 & 3)                                     # cout within a 32-cout pair of blocks, + 4 h
+
+    def gather(w, cout, k):                                               # w [rows][k_pad] -> w[cout, k] broadcast, int16 view
+        return w.view(torch.int16)[cout.to(dev), k.to(dev)].contiguous().view(w.dtype).reshape(-1)
+
+    # w1f [ks][b][lq][l16][e]
+    ks, b = torch.arange(cin // 32), torch.arange(p // 16)
+    cout1 = (32 * (b >> 1) + 4 * (b & 1))[None, :, None, None, None] + pair[None, None, None, :, None]
+    k1 = (32 * ks)[:, None, None, None, None] + (8 * lq)[None, None, :, None, None] + e[None, None, None, None, :]
+    w1f = gather(c1.weight, cout1.expand(len(ks), len(b), 4, 16, 8), k1.expand(len(ks), len(b), 4, 16, 8))
+    # w2f [cg][s][kh][h][lq][l16][e]
+    cw = 16 if p == 64 else 32
+    ncb, ncg, ns = cw // 16, p // cw, (p // 64) * 6
+    cg, st, kh, hh = torch.arange(ncg), torch.arange(ns), torch.arange(3), torch.arange(ncb)
+    c64, kw, hf = st // 6, (st % 6) >> 1, st & 1
+    row = (pair[None, :] + 4 * hh[:, None]) if ncb == 2 else l16[None, :].expand(1, 16)                  # [h][l16]
+    cout2 = (cw * cg)[:, None, None, None, None, None, None] + row[None, None, None, :, None, :, None]
+    k2 = (((3 * c64)[:, None] + kh[None, :]) * 3 + kw[:, None]) * 64 + (32 * hf)[:, None]                 # [s][kh]
+    k2 = k2[None, :, :, None, None, None, None] + (8 * lq)[None, None, None, None, :, None, None] + e[None, None, None, None, None, None, :]
+    shape2 = (ncg, ns, 3, ncb, 4, 16, 8)
+    w2f = gather(c2.weight, cout2.expand(shape2), k2.expand(shape2))
+    # w3f [g][ks][h][lq][l16][e]
+    g32, ks3, h2 = torch.arange(4 * p // 32), torch.arange(p // 32), torch.arange(2)
+    cout3 = (32 * g32)[:, None, None, None, None, None] + (4 * h2)[None, None, :, None, None, None] + pair[None, None, None, None, :, None]
+    k3 = (32 * ks3)[None, :, None, None, None, None] + (8 * lq)[None, None, None, :, None, None] + e[None, None, None, None, None, :]
+    shape3 = (len(g32), len(ks3), 2, 4, 16, 8)
+    w3f = gather(c3.weight, cout3.expand(shape3), k3.expand(shape3))
+    c1.__dict__['_bneck_fm'] = (c2, c3, (w1f, w2f, w3f))
+    return w1f, w2f, w3f
+
+
 def bottleneck(x, c1, c2, c3, residual):
     """relu(c3(relu(c2(relu(c1(x))))) + residual) -- one ResNet bottleneck block (stride 1) in ONE launch."""
     _need_cuda(x, residual)
@@ -308,12 +356,16 @@ def bottleneck(x, c1, c2, c3, residual):
     n, h, w, cin = x.shape
     p = c1.cout
     out = torch.empty((n, h, w, 4 * p), dtype=x.dtype, device=x.device)
+    fm = pack_bottleneck_weights(c1, c2, c3) if BNECK_FRAGMENT_MAJOR else None      # (built once per block: cached on c1)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    T.bottleneck_fused(x, residual, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, out, p, c1.k_pad, c2.k_pad, c3.k_pad,
-                       c1.cout_pad, c2.cout_pad, c3.cout_pad)
+    if fm is not None:
+        T.bottleneck_fused_fm(x, residual, fm[0], c1.bias, fm[1], c2.bias, fm[2], c3.bias, out, p)
+    else:
+        T.bottleneck_fused(x, residual, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, out, p, c1.k_pad, c2.k_pad, c3.k_pad,
+                           c1.cout_pad, c2.cout_pad, c3.cout_pad)
     if prof is not None:
         e1.record()
         prof.records.append(('bneck_kernel', 2.0 * n * h * w * (cin * p + 9 * p * p + 4 * p * p), e0, e1))

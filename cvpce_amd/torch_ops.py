@@ -105,6 +105,15 @@ def _conv3x3_halo_masked(x, weight, bias, mask, tile_map, out, cout, k_pad, cout
              _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, _stream()), 'cvpce_conv3x3_halo_masked')
 
 
+@_op('bottleneck_fused_fm(Tensor x, Tensor res, Tensor w1f, Tensor b1, Tensor w2f, Tensor b2, Tensor w3f, Tensor b3, Tensor(a!) out, int planes) -> ()')
+def _bottleneck_fused_fm(x, res, w1f, b1, w2f, b2, w3f, b3, out, planes):
+    n, h, w, cin = x.shape
+    if w1f.numel() != planes * cin or w2f.numel() != 9 * planes * planes or w3f.numel() != 4 * planes * planes:
+        raise RuntimeError('cvpce_bottleneck_fused_fm: fragment-major weights of the wrong size')
+    fn = _by_dtype(x, 'cvpce_bottleneck_fused_fm', 'cvpce_bottleneck_fused_fm_f16', res, w1f, w2f, w3f, out)
+    check(fn(_p(x), _p(res), _p(w1f), _p(b1), _p(w2f), _p(b2), _p(w3f), _p(b3), _p(out), n, h, w, cin, planes, _stream()), 'cvpce_bottleneck_fused_fm')
+
+
 @_op('bottleneck_fused(Tensor x, Tensor res, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor w3, Tensor b3, Tensor(a!) out, int planes, '
      'int k1_pad, int k2_pad, int k3_pad, int c1_pad, int c2_pad, int c3_pad) -> ()')
 def _bottleneck_fused(x, res, w1, b1, w2, b2, w3, b3, out, planes, k1_pad, k2_pad, k3_pad, c1_pad, c2_pad, c3_pad):

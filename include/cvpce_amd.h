@@ -135,6 +135,17 @@ int cvpce_bottleneck_fused(const void* x, const void* res, const void* w1, const
                            const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, int k1_pad, int k2_pad,
                            int k3_pad, int c1_pad, int c2_pad, int c3_pad, void* stream);
 
+/* The same block with FRAGMENT-MAJOR weights (round 5): every MFMA weight fragment the kernel loads is one contiguous KiB (lane
+ * L = 16 lq + l16 at byte 16 L, 8 consecutive k per lane) -- read from the row-major tensors a fragment is 16 rows x 64 bytes, which the
+ * texture addresser serves one lane per clock.  No padding rows or columns:
+ *   w1 [Cin/32 K-steps ks][P/16 cout blocks b][lane][8]:  cout = 32 (b >> 1) + 8 (l16 >> 2) + (l16 & 3) + 4 (b & 1),  k = 32 ks + 8 lq + e
+ *   w2 [P/CW groups cg][6 P/64 steps s = 6 c64 + 2 kw + half][kh][CW/16 blocks h][lane][8]:  CW = 16 at P = 64, else 32;
+ *        cout = CW cg + (CW == 32 ? 8 (l16 >> 2) + (l16 & 3) + 4 h : l16),  k = ((3 c64 + kh) 3 + kw) 64 + 32 half + 8 lq + e (chunk-major K)
+ *   w3 [4P/32 groups g][P/32 K-steps ks][2 blocks h][lane][8]:  cout = 32 g + 8 (l16 >> 2) + (l16 & 3) + 4 h,  k = 32 ks + 8 lq + e
+ * (writer: cvpce_amd/ops.py pack_bottleneck_weights).  Results are bit-identical to cvpce_bottleneck_fused. */
+int cvpce_bottleneck_fused_fm(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
+                              const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, void* stream);
+
 /* Upper bound on the workgroups the persistent convolution kernels launch (default 256 = one per CU).  A host that
  * runs them on a stream restricted to fewer CUs (hipExtStreamCreateWithCUMask) sets the bound to that CU count.
  * Process-wide; 1 <= n <= 256. */
@@ -322,6 +333,8 @@ int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const float* bias, co
                           int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
 int cvpce_conv3x3_halo_thin_out_f16(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W,
                                     int Cin, int Cout, int K_pad, int Cout_pad, void* stream);
+int cvpce_bottleneck_fused_fm_f16(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,
+                                  const void* w3, const float* b3, void* out, int N, int H, int W, int Cin, int P, void* stream);
 int cvpce_conv1x1_nhwc_f16(const void* in, const void* wgt, const float* bias, const void* res, void* out, int N, int H,
                            int W, int Cin, int Cout, int stride, int Ho, int Wo, int K_pad, int Cout_pad, int relu,
                            int res_mode, int Hr, int Wr, void* stream);

@@ -936,9 +936,13 @@ def test_bottleneck_fused_parity(cuda, dtype, n, cin, p, h, w, sep):
     ops.FUSED_BOTTLENECK_MAX_PLANES = 256          # the detector only uses P = 64 (the measured win); the kernel is verified for all three widths
     try:
         assert ops.can_fuse_bottleneck(xd, *pcs, rdv)
-        y = ops.bottleneck(xd, *pcs, rdv)
+        y = ops.bottleneck(xd, *pcs, rdv)                   # fragment-major weights (round 5, the default)
+        ops.BNECK_FRAGMENT_MAJOR = False
+        y_rm = ops.bottleneck(xd, *pcs, rdv)                # the same kernel reading the row-major weights: the same products in the same order
     finally:
         ops.FUSED_BOTTLENECK_MAX_PLANES = saved
+        ops.BNECK_FRAGMENT_MAJOR = True
+    assert torch.equal(y.view(torch.int16), y_rm.view(torch.int16))
     ops.USE_FUSED_BOTTLENECK = False
     try:
         m1 = ops.conv2d(xd, pcs[0], act=1)

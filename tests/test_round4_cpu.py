@@ -105,3 +105,31 @@ def test_fitted_head_fixture_detects_products_in_the_oracle():
     assert float(m['ap']) >= 0.7 and float(m['ar_300']) >= 0.9, m
     conf = [int((r['scores'] > 0.5).sum()) for r in res]
     assert all(0.5 * len(sc[1]) <= c <= 3 * len(sc[1]) for c, sc in zip(conf, scenes)), (conf, [len(sc[1]) for sc in scenes])   # a bimodal score field
+
+
+def test_bottleneck_fragment_major_packer():
+    """`ops.pack_bottleneck_weights` (round 5: the fused bottleneck reads fragment-major weights) against the index formulas of
+    include/cvpce_amd.h cvpce_bottleneck_fused_fm, for the three widths the kernel is instantiated for: every weight exactly once, and the
+    element at a hand-computed (fragment, lane, e) position is the weight the formula names."""
+    import torch
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for p, cin in ((64, 64), (64, 256), (128, 512), (256, 1024)):
+        c1 = ops.PackedConv(torch.randn(p, cin, 1, 1, generator=g), torch.zeros(p), 1, 0, device='cpu')
+        c2 = ops.PackedConv(torch.randn(p, p, 3, 3, generator=g), torch.zeros(p), 1, 1, device='cpu')
+        c3 = ops.PackedConv(torch.randn(4 * p, p, 1, 1, generator=g), torch.zeros(4 * p), 1, 0, device='cpu')
+        w1f, w2f, w3f = ops.pack_bottleneck_weights(c1, c2, c3)
+        assert ops.pack_bottleneck_weights(c1, c2, c3)[0] is w1f                       # cached on the block
+        for f, c, rows, k in ((w1f, c1, p, cin), (w2f, c2, p, 9 * p), (w3f, c3, 4 * p, p)):
+            assert f.numel() == rows * k
+            assert torch.equal(f.view(torch.int16).sort().values, c.weight[:rows, :k].contiguous().view(torch.int16).reshape(-1).sort().values)
+        ks, b, lq, l16, e = 1, 3, 2, 5, 3
+        assert w1f[(((ks * (p // 16) + b) * 64 + 16 * lq + l16) * 8) + e] == c1.weight[32 * (b >> 1) + 8 * (l16 >> 2) + (l16 & 3) + 4 * (b & 1), 32 * ks + 8 * lq + e]
+        gg, ks, h, lq, l16, e = 2, 1, 1, 3, 9, 7
+        assert w3f[((((gg * (p // 32) + ks) * 2 + h) * 64 + 16 * lq + l16) * 8) + e] == c3.weight[32 * gg + 8 * (l16 >> 2) + (l16 & 3) + 4 * h, 32 * ks + 8 * lq + e]
+        cw = 16 if p == 64 else 32
+        ncb, ns = cw // 16, (p // 64) * 6
+        cg, st, kh, h, lq, l16, e = (p // cw) - 1, ns - 1, 2, ncb - 1, 1, 6, 2
+        c64, kw, hf = st // 6, (st % 6) >> 1, st & 1
+        cout = cw * cg + ((8 * (l16 >> 2) + (l16 & 3) + 4 * h) if ncb == 2 else l16)
+        assert w2f[((((((cg * ns + st) * 3 + kh) * ncb + h) * 64) + 16 * lq + l16) * 8) + e] == c2.weight[cout, ((3 * c64 + kh) * 3 + kw) * 64 + 32 * hf + 8 * lq + e]
