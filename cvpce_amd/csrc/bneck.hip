@@ -261,13 +261,20 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
 #pragma unroll
             for (int r = 0; r < HR; ++r) acc3[h][r] = bias;
         }
-        // residual of this lane's 8 couts at its 7 pixels: in flight under the MFMAs
+        // residual of this pass's 32 couts at its 7 rows of 16 pixels: in flight under the MFMAs.  An accumulator lane (pixel l16, cout
+        // group lq) needs 16 bytes of ITS pixel, and neighbouring lanes are neighbouring pixels 8 P bytes apart -- loaded that way no two
+        // neighbouring lanes share a 64-byte block and the texture addresser takes the load one lane per clock (see FM above).  Instead
+        // lane 4 p + q loads cout group q of pixel p (four neighbouring lanes = one 64-byte run) and the pieces are exchanged across the
+        // wave just before they are added (4 ds_bpermute per row); the stores go the same way round.
+        const int tp = lane >> 2, tq = lane & 3;                      // transposed role: pixel tp, cout group tq
+        const int tox = x0 + tp;
+        const bool tcol_ok = tp < BT && tox < a.W;
         u32x4 resv[HR];
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
             const int oy = y0 + rbase + r;
-            const bool ok = col_ok && oy < a.H;
-            const unsigned off = ok ? (unsigned)((((size_t)(n * a.H + oy) * a.W + ox) * (4 * P) + c0 + 8 * lq) * 2) : 0xFFFFFFF0u;
+            const bool ok = tcol_ok && oy < a.H;
+            const unsigned off = ok ? (unsigned)((((size_t)(n * a.H + oy) * a.W + tox) * (4 * P) + c0 + 8 * tq) * 2) : 0xFFFFFFF0u;
             resv[r] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, off, 0, 0);
         }
         bf16x8 A3[2][2];
@@ -289,11 +296,15 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
             }
         }
 #undef BN_LOAD_A3
+        const int to_acc = (4 * l16 + lq) * 4;                        // byte address of the lane that loaded THIS lane's (pixel l16, group lq) piece
+        const int to_run = (16 * tq + tp) * 4;                        // ... of the accumulator lane that holds the piece THIS lane stores
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
             const int oy = y0 + rbase + r;
-            if (!(col_ok && oy < a.H)) continue;
-            const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[r]);
+            u32x4 rraw;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) rraw[d] = (unsigned)__builtin_amdgcn_ds_bpermute(to_acc, (int)resv[r][d]);
+            const bf16x8 rv = __builtin_bit_cast(bf16x8, rraw);
             f32x4 lo = acc3[0][r], hi = acc3[1][r];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -301,7 +312,13 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
                 hi[j] = relu_bits(hi[j] + E::widen(rv[4 + j]));
             }
             const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(lo)), h2 = __builtin_bit_cast(uint2, E::pack4(hi));
-            *reinterpret_cast<u32x4*>(a.out + ((size_t)(n * a.H + oy) * a.W + ox) * (4 * P) + c0 + 8 * lq) = u32x4{l2.x, l2.y, h2.x, h2.y};
+            u32x4 v;
+            v[0] = (unsigned)__builtin_amdgcn_ds_bpermute(to_run, (int)l2.x);
+            v[1] = (unsigned)__builtin_amdgcn_ds_bpermute(to_run, (int)l2.y);
+            v[2] = (unsigned)__builtin_amdgcn_ds_bpermute(to_run, (int)h2.x);
+            v[3] = (unsigned)__builtin_amdgcn_ds_bpermute(to_run, (int)h2.y);
+            if (tcol_ok && oy < a.H)
+                *reinterpret_cast<u32x4*>(a.out + ((size_t)(n * a.H + oy) * a.W + tox) * (4 * P) + c0 + 8 * tq) = v;
         }
     }
 }
