@@ -2,8 +2,8 @@
 // -- torchvision resnet50 `Bottleneck` (v1.5, stride 1) with FrozenBatchNorm2d folded into the weights, the block the
 // detector's body is made of (reached from cvpce/models/proposals.py:202-216 `resnet_fpn_backbone`).  Instantiated for
 // P = 64 / 128 / 256 (layer1 / layer2 / layer3; layer4's 512-wide intermediates do not fit the LDS) and verified for all
-// three; the detector USES it for layer1 only (cvpce_amd/ops.py FUSED_BOTTLENECK_MAX_PLANES): at P = 128 / 256 a tile is a
-// 107 / 317 us serial chain and a 100x100 / 50x50 map has too few tiles to hide it (profiles/r03_rejected_experiments.md).
+// three; the detector USES it for layer1 and (since the fragment-major weights of round 5) layer2 (cvpce_amd/ops.py
+// FUSED_BOTTLENECK_MAX_PLANES): at P = 256 a tile is a ~110 us serial chain and a 50x50 map has too few tiles to hide it.
 //
 // Why: as three launches the block moves its two P-channel intermediates through HBM (and pays three launch latencies on
 // the detector's critical chain: at 1-8 images per batch these launches are 15-100 us each and HBM- or latency-bound,
@@ -90,13 +90,20 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
     // stage A: mid1 = relu(W1 . x + b1) on the 16 x 16 halo tile; wave w owns halo rows 2w, 2w+1 and all P couts
     // =====================================================================================================================
     {
+        // x fragments: an MFMA lane (pixel l16, K-quarter lq) needs 16 bytes of ITS pixel -- loaded that way neighbouring lanes are
+        // neighbouring pixels 2 Cin bytes apart (one lane per clock in the texture addresser).  Lane 4 p + q loads quarter q of pixel p
+        // instead (64-byte runs) and the pieces are exchanged across the wave when a K-step is consumed (4 ds_bpermute per fragment).
         unsigned xoff[2];
-        bool xin[2];
+        bool xin[2];                  // (of the ACCUMULATOR lane's pixel: the epilogue's zero mask)
+        bool xin_t[2];                // (of the pixel this lane LOADS)
+        const int xtp = lane >> 2, xtq = lane & 3;
+        const int x_to_frag = (4 * l16 + lq) * 4;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int iy = y0 - 1 + 2 * wid + nt, ix = x0 - 1 + l16;
+            const int iy = y0 - 1 + 2 * wid + nt, ix = x0 - 1 + l16, ixt = x0 - 1 + xtp;
             xin[nt] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            xoff[nt] = xin[nt] ? (unsigned)((((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lq * 8) * 2) : 0xFFFFFFF0u;
+            xin_t[nt] = (unsigned)iy < (unsigned)a.H && (unsigned)ixt < (unsigned)a.W;
+            xoff[nt] = xin_t[nt] ? (unsigned)((((size_t)(n * a.H + iy) * a.W + ixt) * a.Cin + xtq * 8) * 2) : 0xFFFFFFF0u;
         }
         unsigned woff[CB1];
 #pragma unroll
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
             A[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w1, FM ? (unsigned)((((KS) * CB1 + 4 * (SG) + i_) * 64 + lane) * 16) : woff[4 * (SG) + i_] + (unsigned)((KS) * 64), 0, 0));
 #define BN_LOAD_B(SLOT, KS)                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                       \
-            B[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xin[i_] ? xoff[i_] + (unsigned)((KS) * 64) : 0xFFFFFFF0u, 0, 0));
+            B[SLOT][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xin_t[i_] ? xoff[i_] + (unsigned)((KS) * 64) : 0xFFFFFFF0u, 0, 0));
 #pragma unroll
         for (int h = 0; h < BD - 1; ++h)
             if (h < nk) BN_LOAD_B(h, h)
@@ -131,6 +138,15 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
                 const int k = ks + h;
                 if (k < nk) {
                     if (k + BD - 1 < nk) BN_LOAD_B(((h + BD - 1) % BD), k + BD - 1)
+                    bf16x8 Bf[2];                                  // this K-step's x fragments in MFMA layout
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const u32x4 raw = __builtin_bit_cast(u32x4, B[h][nt]);
+                        u32x4 v;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) v[d] = (unsigned)__builtin_amdgcn_ds_bpermute(x_to_frag, (int)raw[d]);
+                        Bf[nt] = __builtin_bit_cast(bf16x8, v);
+                    }
 #pragma unroll
                     for (int sg = 0; sg < SG1; ++sg) {
                         const int slot = (h * SG1 + sg) & 1;
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void bneck_kernel(BneckArgs a) {
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt)
-                                acc[4 * sg + i][nt] = E::mfma16(A[slot][i], B[h][nt], acc[4 * sg + i][nt]);
+                                acc[4 * sg + i][nt] = E::mfma16(A[slot][i], Bf[nt], acc[4 * sg + i][nt]);
                     }
                 }
             }

@@ -283,7 +283,7 @@ USE_THIN_3X3 = _os.environ.get('CVPCE_THIN_3X3', '1') != '0'   # A/B switch: the
 USE_FUSED_BOTTLENECK = _os.environ.get('CVPCE_FUSED_BOTTLENECK', '1') != '0'   # A/B switch: stride-1 ResNet bottlenecks (P <= 256) in one launch (csrc/bneck.hip)
 
 
-FUSED_BOTTLENECK_MAX_PLANES = int(_os.environ.get('CVPCE_FUSED_BOTTLENECK_MAXP', '64'))   # measured (tools/dev/bench_bneck.py, profiles/r03_bneck.md): layer1 (P = 64) wins, P = 128 / 256 lose -- their tiles are too few and too long
+FUSED_BOTTLENECK_MAX_PLANES = int(_os.environ.get('CVPCE_FUSED_BOTTLENECK_MAXP', '128'))   # measured (tools/dev/bench_bneck.py): with fragment-major weights (round 5) layer1 (P = 64: 66 vs 88 us per 4-image block) AND layer2 (P = 128: 49 vs 70 us) win over three launches; P = 256 still loses (120 vs 67 us: a 50 x 50 map has too few tiles for a 110-us tile chain).  Round 3-4 (row-major weights): only P = 64 won
 
 
 def can_fuse_bottleneck(x, c1, c2, c3, residual):

@@ -4,8 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from cvpce_amd import ops
 dev = torch.device('cuda')
+ops.FUSED_BOTTLENECK_MAX_PLANES = 256          # (the product fuses P = 64 only: this tool measures all three widths)
+dt = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == 'fp16') else torch.bfloat16
 g = torch.Generator().manual_seed(0)
-mk = lambda co, ci, k: ops.PackedConv(torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k), torch.randn(co, generator=g) * 0.1, 1, k // 2, device=dev)
+mk = lambda co, ci, k: ops.PackedConv(torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k), torch.randn(co, generator=g) * 0.1, 1, k // 2, device=dev, dtype=dt)
 
 
 def timeit(fn, iters=20):
@@ -25,7 +27,7 @@ def timeit(fn, iters=20):
 for p, hw in ((64, 200), (128, 100), (256, 50)):
     cs = (mk(p, 4 * p, 1), mk(p, p, 3), mk(4 * p, p, 1))
     for n in (1, 4, 8):
-        x = torch.randn(n, hw, hw, 4 * p, generator=g).to(torch.bfloat16).to(dev).relu()
+        x = torch.randn(n, hw, hw, 4 * p, generator=g).to(dt).to(dev).relu()
         fused = timeit(lambda: ops.bottleneck(x, *cs, x))
         def unf():
             ops.USE_FUSED_BOTTLENECK = False
