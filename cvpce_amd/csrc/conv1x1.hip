@@ -261,9 +261,15 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_wreg_kernel(C1Args a) {
     bf16x8 af[2 * KS64][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+#ifdef C1_ABL_WFM      /* timing-only ablation: the weight fragments as contiguous KiB (wrong values) -- what a fragment-major copy would cost */
+        const unsigned ao = (unsigned)(((ct * 4 + mt) * 2 * KS64) * 1024 + lane * 16);
+#pragma unroll
+        for (int k = 0; k < 2 * KS64; ++k) af[k][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w, ao, k * 1024, 0));
+#else
         const unsigned ao = (unsigned)(((ct * 64 + 16 * (l16 >> 2) + 4 * mt + (l16 & 3)) * a.K_pad + lq * 8) * 2);
 #pragma unroll
         for (int k = 0; k < 2 * KS64; ++k) af[k][mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_w, ao, k * 64, 0));
+#endif
     }
     f32x4 bias4[4];
 #pragma unroll
