@@ -42,8 +42,14 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, const f32x4 (&acc)[
                 const int n = m / hw, r = m - n * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
                 rp = (size_t)(n * a.Hr + (oy * a.Hr) / a.Ho) * a.Wr + (ox * a.Wr) / a.Wo;
             }
+#ifdef C1_ABL_ST       /* timing-only ablation: residual pieces and stores as lane-contiguous runs (wrong addresses inside the tile's rows) */
+            const size_t ab_ = ((size_t)(pt * 64 + nt * 16) * a.Cout + (size_t)ct * 64) + (size_t)(threadIdx.x & 63) * 16;
+            const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(a.res + (a.res_mode == 2 ? rp * a.Cout + co : ab_));
+            const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(a.res + (a.res_mode == 2 ? rp * a.Cout + co : ab_) + 8);
+#else
             const bf16x8 r0 = *reinterpret_cast<const bf16x8*>(a.res + rp * a.Cout + co);
             const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(a.res + rp * a.Cout + co + 8);
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[j] += E::widen(r0[j]); v[8 + j] += E::widen(r1[j]); }
         }
@@ -57,7 +63,11 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, const f32x4 (&acc)[
             const uint2 u = __builtin_bit_cast(uint2, E::pack4(f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}));
             pk[2 * g] = u.x; pk[2 * g + 1] = u.y;
         }
+#ifdef C1_ABL_ST
+        bf16_t* dst = a.out + ((size_t)(pt * 64 + nt * 16) * a.Cout + (size_t)ct * 64) + (size_t)(threadIdx.x & 63) * 16;
+#else
         bf16_t* dst = a.out + (size_t)m * a.Cout + co;
+#endif
         *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
         *reinterpret_cast<u32x4*>(dst + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
     }
