@@ -1006,6 +1006,18 @@ def main():
         print(json.dumps(line), flush=True)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
+        # Rank 0 runs its side legs (roofline, parity, CPU baseline: ~2 min) after the last collective; the other ranks have nothing left to
+        # do.  They wait for rank 0 on the rendezvous STORE (a host-side key, no collective, nothing spinning on their GPUs) so that every
+        # rank tears its process group down while all peers are still alive.
+        try:
+            import datetime
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set('cvpce_bench_done', '1')
+            else:
+                store.wait(['cvpce_bench_done'], datetime.timedelta(seconds=3600))
+        except Exception:                         # noqa: BLE001 (a missing store API only loses the orderly teardown)
+            pass
         dist.destroy_process_group()
 
 
