@@ -853,7 +853,7 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
     dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
     ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
-    if k == 1 and queries.dtype == BF16 and qn <= MATCH_STATE_QUERIES:
+    if k == 1 and queries.dtype == BF16 and qn <= MATCH_STATE_QUERIES and (_match_state_key(queries.device) in _MATCH_STATE or not torch.cuda.is_current_stream_capturing()):
         # the one-launch form: a state block per (device, stream) -- launches of one stream are ordered, so they can share a block
         T.match_topk_state(queries, gallery, q_norms, g_norms, k, ws, match_state(queries.device), idx, dist)
     else:
@@ -865,10 +865,15 @@ MATCH_STATE_QUERIES = 16384      # queries per launch the one-launch top-1 searc
 _MATCH_STATE = {}
 
 
+def _match_state_key(device):
+    return (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+
+
 def match_state(device):
     """The persistent state block of the one-launch top-1 search for the CURRENT stream of `device` (include/cvpce_amd.h
-    cvpce_match_topk_state): initialised once, restored by every launch that uses it."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    cvpce_match_topk_state): initialised once, restored by every launch that uses it.  (Never created inside a stream capture -- its
+    memory would belong to that graph's pool: a capture on a stream without a block takes the plain two-launch entry point.)"""
+    key = _match_state_key(device)
     st = _MATCH_STATE.get(key)
     if st is None:
         st = torch.empty(lib.cvpce_match_state_bytes(MATCH_STATE_QUERIES) // 8, dtype=torch.int64, device=device)
