@@ -13,12 +13,17 @@ cases = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(200, 10
                                                                         (1600, 10000, 512), (1600, 10000, 1024), (1600, 3200, 1024), (1600, 1000, 1024), (3200, 10000, 1024)]
 
 
+SIDE = torch.cuda.Stream()        # warm-up and capture on ONE stream: the one-launch form's state block is per stream and is never created inside a capture
+
+
 def timed(q, gal, qn, gn, per_graph=20, reps=10):
-    for _ in range(3):
-        ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
+    SIDE.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(SIDE):
+        for _ in range(3):
+            ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+    with torch.cuda.graph(graph, stream=SIDE, capture_error_mode='thread_local'):
         for _ in range(per_graph):
             ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn)
     graph.replay(); torch.cuda.synchronize()
