@@ -658,6 +658,24 @@ class GaussianLayerNetwork(nn.Module):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
+    @torch.no_grad()
+    def saturation_report(self, images):
+        """Diagnostic for the fp16 storage mode (the default): fp16 stores SATURATE at +-65504 instead of overflowing, silently.  Runs one
+        eager pass over `images` and reports, per stage the schedule keeps in 16-bit storage (C2 ... C5 of the body, the five FPN maps),
+        the largest magnitude and the fraction of elements at the saturation value.  A checkpoint whose activations come near 65504
+        should run with `set_precision('bf16')` (8 exponent bits).  Seeded and fitted weights here stay below 1e3.
+        -> {'precision', 'stages': {name: {'max_abs', 'saturated_fraction'}}, 'saturated': bool}"""
+        eng = self.engine()
+        images = [i.to(device=eng.device, dtype=torch.float32) for i in (list(images) if torch.is_tensor(images) else images)]
+        _, inter = eng.detect(images, self.num_classes, self.detections_per_img, want_intermediates=True)
+        self.backbone.gaussians = None
+        limit = 65504.0 if self.precision == 'fp16' else float(torch.finfo(torch.bfloat16).max)
+        stages = {}
+        for name, t in list(zip(('c2', 'c3', 'c4', 'c5'), inter['c'])) + [(f'fpn{i}', f) for i, f in enumerate(inter['features'])]:
+            a = t.float().abs()
+            stages[name] = {'max_abs': float(a.max()), 'saturated_fraction': float((a >= limit).float().mean())}
+        return {'precision': self.precision, 'stages': stages, 'saturated': any(v['saturated_fraction'] > 0 for v in stages.values())}
+
     def engine(self):
         dev = next(self.parameters()).device
         if dev.type != 'cuda':

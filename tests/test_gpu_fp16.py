@@ -266,3 +266,22 @@ def test_fp16_detector_portrait_tanh_batch_of_mixed_sizes(cuda):
         assert d.norm() / o['gaussians'].norm() < 0.01 and d.abs().max() < 0.1, (float(d.norm() / o['gaussians'].norm()), float(d.abs().max()))
         pairs = accuracy.pair_boxes(h['boxes'].cpu(), o['boxes'])
         assert len(pairs) >= 0.9 * len(o['boxes']), (len(pairs), len(o['boxes']))     # (100 boxes per image: one near-tie flip is a point)
+
+
+def test_saturation_report(cuda):
+    """fp16 stores saturate at +-65504 silently (csrc/common.h ElemF16): `GaussianLayerNetwork.saturation_report` is the diagnostic a
+    maintainer runs on a real checkpoint before trusting the default fp16 storage.  Seeded weights stay far below the limit; with the
+    stem's weights scaled up 1e4 x the report flags the saturated stages -- and bf16 storage (8 exponent bits) does not saturate on them."""
+    from cvpce_amd import synthetic
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=20).to(cuda)
+    img = synthetic.shelf_image(5, 320, 320).to(cuda)
+    rep = det.saturation_report([img])
+    assert rep['precision'] == 'fp16' and not rep['saturated'] and set(rep['stages']) == {'c2', 'c3', 'c4', 'c5', 'fpn0', 'fpn1', 'fpn2', 'fpn3', 'fpn4'}
+    assert all(0 < v['max_abs'] < 6.5e4 for v in rep['stages'].values())
+    with torch.no_grad():
+        det.backbone.body.conv1.weight.mul_(1e4)
+    det._engine = None
+    hot = det.saturation_report([img])
+    assert hot['saturated'] and hot['stages']['c2']['saturated_fraction'] > 0 and hot['stages']['c2']['max_abs'] == 65504.0
+    det.set_precision('bf16')
+    assert not det.saturation_report([img])['saturated']
