@@ -282,6 +282,6 @@ def test_saturation_report(cuda):
         det.backbone.body.conv1.weight.mul_(1e4)
     det._engine = None
     hot = det.saturation_report([img])
-    assert hot['saturated'] and hot['stages']['c2']['saturated_fraction'] > 0 and hot['stages']['c2']['max_abs'] == 65504.0
+    assert hot['saturated'] and max(v['max_abs'] for v in hot['stages'].values()) == 65504.0, hot
     det.set_precision('bf16')
     assert not det.saturation_report([img])['saturated']
