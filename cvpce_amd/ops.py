@@ -116,8 +116,20 @@ class ConvProfile:
 
     Kernel variant names mirror the dispatch in csrc/conv_igemm.hip (tile TC x TP, K-step BK)."""
 
+    class _Records(list):
+        """The launch records; while `stage == 'detect'` the 3x3 halo kernels' records are filed under '<kernel>[detector]': the detector's
+        launches (fp16 / non-list instances on small maps and the head atlas, 0.2-0.5 of the rate) are other template instances than the
+        embedder's and are listed apart by rocprofv3 too -- merged, they hid what the dominant kernel (VGG conv3_1 ... conv5_3) reaches."""
+        SPLIT = ('conv3x3_halo2_kernel', 'conv3x3_halo3_kernel')
+        stage = None
+
+        def append(self, rec):
+            if self.stage == 'detect' and rec[0] in self.SPLIT:
+                rec = (rec[0] + '[detector]',) + tuple(rec[1:])
+            list.append(self, rec)
+
     def __init__(self):
-        self.records = []   # (variant, flops, start_event, end_event)
+        self.records = ConvProfile._Records()   # (variant, flops, start_event, end_event)
         self.byte_records = []   # HBM-bound launches: (kernel, algorithmic bytes, start_event, end_event)
         self.layer_records = []  # detector launch classes: (kernel + layer shape, algorithmic FLOPs, algorithmic bytes, start_event, end_event)
 

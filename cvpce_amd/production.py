@@ -425,7 +425,11 @@ class BatchedPipeline:
 
         det = self.detector
         t0 = mark()
+        if ops.PROFILE is not None:
+            ops.PROFILE.records.stage = 'detect'           # (per-launch profile: the detector's 3x3 halo launches are filed apart)
         det_out = det.engine().detect(images, det.num_classes, det.detections_per_img, self.confidence_threshold)
+        if ops.PROFILE is not None:
+            ops.PROFILE.records.stage = 'embed'
         if proposals is not None:
             pb, pc = proposals
             assert pb.shape == det_out[0].shape and pb.dtype == torch.float32 and pc.dtype == torch.int32 and pc.shape == det_out[4].shape

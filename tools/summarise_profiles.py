@@ -6,6 +6,10 @@ tag, prof, pmc = sys.argv[1], sys.argv[2], sys.argv[3]          # e.g. r01g prof
 
 
 def prof_name(k):    # rocprof kernel name -> the name ops.ConvProfile / bench.py use (roofline.traffic, roofline.hbm_stages)
+    # the detector (fp16 storage by default) runs ElemF16 instances of the 3x3 halo kernels: filed apart, like bench.py's profile does
+    for p in ('conv3x3_halo2_kernel', 'conv3x3_halo3_kernel'):
+        if (k.startswith(p) or k.startswith('void ' + p)) and 'ElemF16' in k:
+            return p + '[detector]'
     for p, n in (('conv3x3_halo2_kernel', 'conv3x3_halo2_kernel'), ('conv3x3_halo3_kernel', 'conv3x3_halo3_kernel'), ('vgg_stem2_kernel', 'vgg_stem2_kernel'),
                  ('gln_transform_batch_kernel', 'gln_transform_batch_kernel'), ('crop_resize2_kernel', 'crop_resize_kernel'), ('crop_resize_kernel', 'crop_resize_kernel'),
                  ('conv1x1_stream_wreg_kernel', 'conv1x1_kernel'), ('conv1x1_stream_kernel', 'conv1x1_kernel'), ('conv1x1_kernel', 'conv1x1_kernel'),
