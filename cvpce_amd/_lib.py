@@ -29,6 +29,8 @@ _ip = c_void_p
 
 SIGNATURES = {
     'cvpce_conv2d_nhwc_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 21 + [_vp]),
+    'cvpce_conv2d_splitk_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 20 + [_vp, c_size_t, _vp]),
+    'cvpce_conv2d_splitk_workspace_bytes': (c_size_t, [c_longlong, c_int, c_int]),
     'cvpce_set_persistent_workgroups': (c_int, [c_int]),
     'cvpce_conv1x1_nhwc_bf16': (c_int, [_vp, _vp, _fp, _vp, _vp] + [c_int] * 14 + [_vp]),
     'cvpce_vgg_stem_fused': (c_int, [_vp, c_int, _vp, _fp, _vp, _fp, _vp, c_int, c_int, c_int, _vp]),
@@ -77,7 +79,7 @@ SIGNATURES = {
     'cvpce_match_topk': (c_int, [_vp, _vp, _fp, _fp, c_int, c_int, c_int, c_int, c_int, _vp, c_size_t, _vp, _fp, _vp]),
 }
 # fp16 twins of the detector's kernels (the opt-in accuracy mode): same argument lists as the functions they are named after
-for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16'),
+for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpce_conv2d_splitk_bf16', 'cvpce_conv2d_splitk_f16'), ('cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16'),
                      ('cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16'), ('cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16'),
                      ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_thin_out', 'cvpce_conv3x3_halo_thin_out_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
                      ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'), ('cvpce_bottleneck_fused_fm', 'cvpce_bottleneck_fused_fm_f16'),

@@ -62,6 +62,9 @@ struct ConvArgs {
     int pool;
     int tiles_p, tiles_c;
     unsigned in_bytes, wgt_bytes;   // buffer-descriptor extents of `in` / `wgt` (LDS-DMA bounds check = zero fill)
+    // split-K launches of the register-staged kernel (small maps with a long K: the launch is a chain of K-steps on a few workgroups)
+    int ksplit;                     // workgroups per output tile, each with nk / ksplit K-steps
+    float* ws;                      // [ksplit][tiles][16 f32x4 per thread][256 threads] fp32 partial tiles, in accumulator-register order
 };
 
 // M index -> (image, oy, ox).  Row-major, or 2x2-quad order when the pool is fused.
@@ -832,8 +835,14 @@ __global__ __launch_bounds__(WC * WP * 64, MINW) void conv_dma16_kernel(ConvArgs
 // ===========================================================================
 // generic register-staged kernel
 // ===========================================================================
-template <typename E, int TC, int TP, int BK, int WC, int WP>
+// SPLIT: a.ksplit workgroups share one output tile, each over its own range of K-steps; every one of them writes its fp32 partial tile
+// to a.ws (in accumulator-register order: 1 KiB per wave and store) and conv_splitk_finish_kernel, the next launch on the stream, adds
+// the partials in split order 0, 1, ... and runs the epilogue.  (One launch with the tile's last-arriving workgroup finishing it was
+// built first: the agent-scope fences it needs around the hand-over -- buffer_wbl2 / buffer_inv of the whole L2, per workgroup -- made
+// the detector 0.24 ms SLOWER per 4 images, profiles/r05_rejected_experiments.md.)
+template <typename E, int TC, int TP, int BK, int WC, int WP, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+    static_assert(!SPLIT || BK == 64, "split launches use the chunk-major K order");
     constexpr int CPR = BK / 8;             // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;          // tile rows covered per staging pass
     constexpr int WPASS = TC / RPP;
@@ -850,7 +859,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wc = wid / WP, wp = wid % WP;
-    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = a.tiles_c * a.tiles_p;
+    int split = 0;
+    if constexpr (SPLIT) {
+        split = swz / ntile;
+        swz -= split * ntile;
+    }
     const int tile_c = swz % a.tiles_c, tile_p = swz / a.tiles_c;
 
     const int c = tid % CPR;
@@ -880,6 +895,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     int kh = tap / a.KW;
     int kw = tap - kh * a.KW;
 
+    const int nk = a.K_pad / BK;
+    int k_begin = 0, k_end = nk;
+    if constexpr (SPLIT) {
+        // this workgroup's K-steps; K-step kt of the chunk-major order is (channel chunk kt / taps, tap kt % taps)
+        const int per = (nk + a.ksplit - 1) / a.ksplit;
+        k_begin = split * per;
+        k_end = k_begin + per < nk ? k_begin + per : nk;
+        const int taps = a.KH * a.KW;
+        const int chunk = k_begin / taps, r = k_begin - chunk * taps;
+        kh = r / a.KW;
+        kw = r - kh * a.KW;
+        ci = chunk * BK + c * 8;
+    }
+
     const bf16_t* wrow = a.wgt + (size_t)(tile_c * TC + r0) * a.K_pad + c * 8;
 
     // Register staging, TWO K-steps deep, and no branch anywhere around a load: the gather goes through a buffer descriptor
@@ -889,7 +918,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // (the same repair as in csrc/match.hip; these small-M layers are pure latency).
     const __amdgpu_buffer_rsrc_t srd_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     u32x4 wreg[2][WPASS], preg[2][PPASS];
-    const int nk = a.K_pad / BK;
 
 #define CVPCE_LOAD_TILE(KT, SLOT)                                                                              \
     {                                                                                                          \
@@ -939,8 +967,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    CVPCE_LOAD_TILE(0, 0)
-    CVPCE_LOAD_TILE(1, 1)
+    CVPCE_LOAD_TILE(k_begin, 0)
+    CVPCE_LOAD_TILE(k_begin + 1, 1)
     CVPCE_STORE_TILE(0, 0)
     __syncthreads();
     int cur = 0;
@@ -957,15 +985,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();                                                                                       \
         cur ^= 1;                                                                                              \
     }
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
+    int kt = k_begin;
+    for (; kt + 1 < k_end; kt += 2) {
         CVPCE_KSTEP(kt, 1)
         CVPCE_KSTEP(kt + 1, 0)
     }
-    if (kt < nk) CVPCE_KSTEP(kt, 1)
+    if (kt < k_end) CVPCE_KSTEP(kt, 1)
 #undef CVPCE_KSTEP
 #undef CVPCE_LOAD_TILE
 #undef CVPCE_STORE_TILE
+    if constexpr (SPLIT) {
+        // (a split whose K range is empty -- ksplit does not divide nk -- still hands in its zeros and takes a ticket)
+        constexpr int Q = MT * NT * 4;                                   // f32x4 per thread
+        f32x4* part = reinterpret_cast<f32x4*>(a.ws) + ((size_t)(split * ntile + swz) * Q) * 256 + tid;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    part[((mt * NT + nt) * 4 + g) * 256] =
+                        f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        return;                                                          // conv_splitk_finish_kernel adds the partial tiles and stores
+    }
     conv_epilogue<E, MT, NT>(a, acc, tile_c * TC + wc * (TC / WC), tile_p * TP + wp * (TP / WP), lane);
 }
 
@@ -977,6 +1019,53 @@ static int launch_conv(const ConvArgs& a0, hipStream_t stream) {
     size_t smem = (size_t)2 * (TC + TP) * BK * sizeof(bf16_t);
     dim3 grid(a.tiles_p * a.tiles_c);
     hipLaunchKernelGGL((conv_igemm_kernel<E, TC, TP, BK, WC, WP>), grid, dim3(256), smem, stream, a);
+    return cvpce_check_launch();
+}
+
+// second launch of a split-K conv: workgroup = output tile, thread = the thread of conv_igemm_kernel<128, 128, 64, 2, 2> that held these
+// accumulators; the partial tiles are added in split order and go through the same epilogue
+template <typename E>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
+    constexpr int MT = 2, NT = 2, Q = MT * NT * 4, WP = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wc = wid / WP, wp = wid % WP;
+    const int tile = blockIdx.x, ntile = a.tiles_c * a.tiles_p;
+    const int tile_c = tile % a.tiles_c, tile_p = tile / a.tiles_c;
+    const f32x4* all = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)tile * Q) * 256 + tid;
+    f32x16 acc[MT][NT];
+    for (int sp = 0; sp < a.ksplit; ++sp) {
+        const f32x4* src = all + (size_t)sp * ntile * Q * 256;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = src[((mt * NT + nt) * 4 + g) * 256];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][nt][4 * g + j] = sp == 0 ? v[j] : acc[mt][nt][4 * g + j] + v[j];
+                }
+    }
+    conv_epilogue<E, MT, NT>(a, acc, tile_c * 128 + wc * 64, tile_p * 128 + wp * 64, lane);
+}
+
+// split-K launch pair of the 128 x 128 register-staged kernel
+template <typename E>
+static int launch_conv_split(const ConvArgs& a0, int ksplit, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_p = (a.M + 127) / 128;
+    a.tiles_c = (a.Cout + 127) / 128;
+    const long long ntile = (long long)a.tiles_p * a.tiles_c;
+    if (ntile * ksplit >= (1LL << 24)) return CVPCE_ERR_ARG;
+    const size_t need = (size_t)ksplit * ntile * 128 * 128 * sizeof(float);
+    if (!workspace || workspace_bytes < need || ((size_t)workspace & 15)) return CVPCE_ERR_ARG;
+    a.ksplit = ksplit;
+    a.ws = (float*)workspace;
+    const size_t smem = (size_t)2 * (128 + 128) * 64 * sizeof(bf16_t);
+    hipLaunchKernelGGL((conv_igemm_kernel<E, 128, 128, 64, 2, 2, true>), dim3((unsigned)(ntile * ksplit)), dim3(256), smem, stream, a);
+    const int rc = cvpce_check_launch();
+    if (rc != CVPCE_OK) return rc;
+    hipLaunchKernelGGL((conv_splitk_finish_kernel<E>), dim3((unsigned)ntile), dim3(256), 0, stream, a);
     return cvpce_check_launch();
 }
 
@@ -1031,7 +1120,8 @@ static int conv2d_dispatch(const void* in, const void* wgt, const float* bias, c
                            void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                            int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
                            int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
-                           int fuse_pool2, int force_generic, void* stream) {
+                           int fuse_pool2, int force_generic, void* stream, int ksplit = 0, void* workspace = nullptr,
+                           size_t workspace_bytes = 0) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || !out) return CVPCE_ERR_ARG;
     if (Cin % 8 != 0 || K_pad % 32 != 0 || (Cin % 64 == 0 && K_pad % 64 != 0) || Cout_pad % 256 != 0 || Cout_pad < Cout)
@@ -1052,10 +1142,16 @@ static int conv2d_dispatch(const void* in, const void* wgt, const float* bias, c
     a.Ho = Ho; a.Wo = Wo; a.K_pad = K_pad; a.M = N * Ho * Wo; a.relu = act; a.out_f32 = out_f32;
     a.in_up_shift = in_up_shift; a.res_mode = res_mode; a.Hr = Hr; a.Wr = Wr; a.pool = fuse_pool2 ? 1 : 0;
     a.tiles_p = a.tiles_c = 0;
+    a.ksplit = 0; a.ws = nullptr;
     a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2);
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     hipStream_t s = (hipStream_t)stream;
     const bool bk64 = (Cin % 64 == 0);
+    if (ksplit) {
+        // the caller asks for the split-K form (cvpce_conv2d_splitk_*): the 128-cout register-staged kernel's shapes only
+        if (ksplit < 2 || ksplit > 16 || !bk64 || Cout <= 64 || fuse_pool2 || ksplit > K_pad / 64) return CVPCE_ERR_ARG;
+        return launch_conv_split<E>(a, ksplit, workspace, workspace_bytes, s);
+    }
     // LDS-DMA workhorse: K-step 64 within one tap, and enough pixel tiles to fill 256 CUs.
     //   Cout >= 192: 8 waves, 256x256 tile, 128 KiB LDS, 1 workgroup / CU (2 waves / SIMD)
     //   Cout <= 128: 4 waves, 128x128 or 64x128 tile, 64 / 48 KiB LDS, 2 workgroups / CU
@@ -1096,3 +1192,31 @@ extern "C" int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const floa
     return conv2d_dispatch<ElemF16>(CVPCE_CONV2D_ARGS);
 }
 #undef CVPCE_CONV2D_ARGS
+
+// Split-K form of the register-staged kernel for small maps with a long K (ResNet-50 layer4's 3x3 convs on 25 x 25 maps, the FPN's
+// P5 / P6 / P7 convs): `ksplit` workgroups per 128 x 128 output tile, fp32 partial tiles through `workspace`, summed in split order by
+// a second launch (results do not vary from run to run; they differ from the unsplit kernel's in the last bits of the fp32 sum).
+// workspace: cvpce_conv2d_splitk_workspace_bytes(M = N Ho Wo, Cout, ksplit) bytes, 16-byte aligned, used by one conv at a time.
+extern "C" size_t cvpce_conv2d_splitk_workspace_bytes(long long M, int Cout, int ksplit) {
+    if (M <= 0 || Cout <= 0 || ksplit < 2) return 0;
+    const long long ntile = ((M + 127) / 128) * ((Cout + 127) / 128);
+    return (size_t)ksplit * ntile * 128 * 128 * sizeof(float);
+}
+extern "C" int cvpce_conv2d_splitk_bf16(const void* in, const void* wgt, const float* bias, const void* res,
+                                        void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                        int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
+                                        int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
+                                        int ksplit, void* workspace, size_t workspace_bytes, void* stream) {
+    if (ksplit < 2) return CVPCE_ERR_ARG;
+    return conv2d_dispatch<ElemBF16>(in, wgt, bias, res, out, N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, K_pad, Cout_pad, act, out_f32,
+                                     in_up_shift, res_mode, Hr, Wr, 0, 0, stream, ksplit, workspace, workspace_bytes);
+}
+extern "C" int cvpce_conv2d_splitk_f16(const void* in, const void* wgt, const float* bias, const void* res,
+                                       void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                       int stride, int pad, int Ho, int Wo, int K_pad, int Cout_pad,
+                                       int act, int out_f32, int in_up_shift, int res_mode, int Hr, int Wr,
+                                       int ksplit, void* workspace, size_t workspace_bytes, void* stream) {
+    if (ksplit < 2) return CVPCE_ERR_ARG;
+    return conv2d_dispatch<ElemF16>(in, wgt, bias, res, out, N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, K_pad, Cout_pad, act, out_f32,
+                                    in_up_shift, res_mode, Hr, Wr, 0, 0, stream, ksplit, workspace, workspace_bytes);
+}

@@ -279,15 +279,39 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
             prof.layer(f'conv1x1 {ho}x{wo} {pc.cin}->{pc.cout} s{pc.stride}' + (' +res' if residual is not None else ''), 2.0 * n * ho * wo * pc.cout * pc.cin,
                        n * ho * wo * cin * x.element_size() + _nbytes(out, residual, pc.weight), e0, e1)
         return out
-    T.conv2d_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
-                  int(act), int(out_f32), int(in_up_shift), int(res_mode), int(pool), int(FORCE_GENERIC_CONV))   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
+    # small maps with a long K (layer4's 3x3 convs on 25 x 25 maps, the stride-2 3x3s that open layer3 / layer4, P5 / P6 / P7): the
+    # register-staged kernel with K split over `ks` workgroups per output tile (csrc/conv_igemm.hip SPLIT)
+    ks = splitk_factor(pc, ho, wo) if (not pool and not FORCE_GENERIC_CONV and ConvProfile.variant(pc, n * ho * wo).startswith('conv_igemm_kernel<128')) else 0
+    if ks:
+        cache = pc.__dict__.setdefault('_splitk_ws', {})        # one workspace per launch shape, never freed (captured graphs hold its address)
+        key = (n, ho, wo, ks, x.device)
+        ws = cache.get(key)
+        if ws is None:
+            ws = cache[key] = torch.empty(int(lib.cvpce_conv2d_splitk_workspace_bytes(n * ho * wo, pc.cout, ks)), dtype=torch.uint8, device=x.device)
+        T.conv2d_splitk(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
+                        int(act), int(out_f32), int(in_up_shift), int(res_mode), ks, ws)
+    else:
+        T.conv2d_nhwc(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
+                      int(act), int(out_f32), int(in_up_shift), int(res_mode), int(pool), int(FORCE_GENERIC_CONV))   # FORCE_GENERIC_CONV: False/True or 2, 3 = A/B variants
     if prof is not None:
         e1.record()
         # algorithmic FLOPs: real (unpadded) channels, 2 FLOP per MAC
         prof.records.append((prof.variant(pc, n * ho * wo), 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, e0, e1))
-        prof.layer(f"{prof.variant(pc, n * ho * wo).split('<')[0]} {ho}x{wo} {pc.cin}->{pc.cout} k{pc.kh} s{pc.stride}" + (' f32 out' if out_f32 else ''),
+        prof.layer(f"{prof.variant(pc, n * ho * wo).split('<')[0]} {ho}x{wo} {pc.cin}->{pc.cout} k{pc.kh} s{pc.stride}" + (' f32 out' if out_f32 else '') + (f' split-K {ks}' if ks else ''),
                    2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin, _nbytes(x, out, residual, pc.weight), e0, e1)
     return out
+
+
+CONV_SPLITK = _os.environ.get('CVPCE_CONV_SPLITK', '1') != '0'   # A/B switch: split-K launches of the register-staged kernel
+
+
+def splitk_factor(pc, ho, wo):
+    """Workgroups per output tile for a conv that the 128-cout register-staged kernel would run: a function of the LAYER shape only
+    (K-steps, map size), 0 = unsplit.  36+ K-steps on an output map of at most 32 x 32: 4 (tools/dev/bench_splitk.py: 62 -> 41 us for layer4's 3x3 on
+    4 images, 34 -> 24 us for P6 / P7; a 50 x 50 output map has workgroups enough and loses 2-10 us to the partial tiles' round trip)."""
+    if not CONV_SPLITK or pc.cin_pad % 64 != 0 or pc.cout <= 64 or pc.k_pad // 64 < 32:
+        return 0
+    return 4 if ho * wo <= 1024 else 0
 
 
 USE_HALO_THIN_OUT = _os.environ.get('CVPCE_HALO_THIN_OUT', '1') != '0'   # A/B switch: the head's output convs through the thin-output form of the wide halo kernel

@@ -60,6 +60,19 @@ def _conv2d_nhwc(x, weight, bias, residual, out, cout, kh, kw, stride, pad, ho, 
              force_generic, _stream()), 'cvpce_conv2d_nhwc')
 
 
+@_op('conv2d_splitk(Tensor x, Tensor weight, Tensor? bias, Tensor? residual, Tensor(a!) out, int cout, int kh, int kw, int stride, '
+     'int pad, int ho, int wo, int k_pad, int cout_pad, int act, int out_f32, int in_up_shift, int res_mode, int ksplit, '
+     'Tensor(b!) workspace) -> ()')
+def _conv2d_splitk(x, weight, bias, residual, out, cout, kh, kw, stride, pad, ho, wo, k_pad, cout_pad, act, out_f32, in_up_shift,
+                   res_mode, ksplit, workspace):
+    n, h, w, cin = x.shape
+    hr, wr = (residual.shape[1], residual.shape[2]) if residual is not None else (0, 0)
+    fn = _by_dtype(x, 'cvpce_conv2d_splitk_bf16', 'cvpce_conv2d_splitk_f16', weight, residual, None if out_f32 else out)
+    check(fn(_p(x), _p(weight), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, kh, kw, stride, pad, ho, wo,
+             k_pad, cout_pad, act, out_f32, in_up_shift, res_mode if residual is not None else 0, hr, wr, ksplit,
+             _p(workspace), workspace.numel() * workspace.element_size(), _stream()), 'cvpce_conv2d_splitk')
+
+
 @_op('conv1x1_nhwc(Tensor x, Tensor weight, Tensor? bias, Tensor? residual, Tensor(a!) out, int cout, int stride, int ho, int wo, '
      'int k_pad, int cout_pad, int relu, int res_mode) -> ()')
 def _conv1x1_nhwc(x, weight, bias, residual, out, cout, stride, ho, wo, k_pad, cout_pad, relu, res_mode):

@@ -49,6 +49,19 @@ int cvpce_conv2d_nhwc_bf16(const void* in, const void* wgt, const float* bias, c
                            int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
                            int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
 
+/* Split-K form of cvpce_conv2d_nhwc_bf16 for small maps with a long K (torchvision ResNet-50 layer4's 3x3 convs on the 25 x 25 maps of
+ * an 800-pixel image, the stride-2 3x3 convs that open layer3 / layer4, the FPN's P5 output conv and P6 / P7 -- proposals.py:109-139
+ * builds them): as the unsplit launch these are a chain of 36-72 K-steps on a few dozen workgroups.  Same operands, layouts and
+ * epilogue (Cin % 64 == 0, Cout > 64, no fused pool); `ksplit` (2..16) workgroups per 128 x 128 output tile, each over nk / ksplit
+ * K-steps, fp32 partial tiles through `workspace`, added in split order by a second launch on the same stream -- the result does not
+ * vary from run to run; it differs from the unsplit kernel's in the last bits of the fp32 sum.  workspace: at least
+ * cvpce_conv2d_splitk_workspace_bytes(N Ho Wo, Cout, ksplit) bytes, 16-byte aligned, one conv at a time. */
+size_t cvpce_conv2d_splitk_workspace_bytes(long long M, int Cout, int ksplit);
+int cvpce_conv2d_splitk_bf16(const void* in, const void* wgt, const float* bias, const void* res, void* out,
+                             int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
+                             int res_mode, int Hr, int Wr, int ksplit, void* workspace, size_t workspace_bytes, void* stream);
+
 /* 1x1 convolution (nn.Conv2d(k=1, stride s, pad 0) of the ResNet-50 bottlenecks / downsample paths, the FPN lateral convs and the
  * Gaussian layer's lateral, proposals.py:68) as a pointwise GEMM: Cin % 64 == 0 (= K_pad), Cout % 64 == 0; same operands, weight
  * layout, residual modes (0 none, 1 same-size add, 2 nearest-upsampled add from [N][Hr][Wr][Cout]) and numerics as
@@ -331,6 +344,10 @@ int cvpce_conv2d_nhwc_f16(const void* in, const void* wgt, const float* bias, co
                           int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
                           int res_mode, int Hr, int Wr, int fuse_pool2, int force_generic, void* stream);
+int cvpce_conv2d_splitk_f16(const void* in, const void* wgt, const float* bias, const void* res, void* out,
+                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                            int Ho, int Wo, int K_pad, int Cout_pad, int act, int out_f32, int in_up_shift,
+                            int res_mode, int Hr, int Wr, int ksplit, void* workspace, size_t workspace_bytes, void* stream);
 int cvpce_conv3x3_halo_thin_out_f16(const void* in, const void* wgt, const float* bias, float* out, int N, int H, int W,
                                     int Cin, int Cout, int K_pad, int Cout_pad, void* stream);
 int cvpce_bottleneck_fused_fm_f16(const void* x, const void* res, const void* w1, const float* b1, const void* w2, const float* b2,

@@ -740,6 +740,58 @@ def test_conv3x3_thin_out_parity(cuda, dtype, n, cin, h, w, cout):
         torch.ops.cvpce_amd.conv3x3_halo_thin_out(xin, pc.weight_halo, pc.bias, torch.empty((n, h, w, 200), dtype=torch.float32, device=cuda), 200, pc.k_pad, pc.cout_pad)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,res,act,f32', [
+    (4, 512, 25, 25, 512, 3, 1, False, 1, False),      # layer4 conv2 (72 K-steps, split 4)
+    (2, 512, 50, 50, 512, 3, 2, False, 1, False),      # layer4's opening stride-2 conv
+    (3, 256, 64, 64, 256, 3, 2, False, 1, False),      # a 32 x 32 output map: the largest that is split
+    (4, 256, 13, 13, 256, 3, 2, False, 0, False),      # P7 from P6: 7 x 7 out, ragged pixel tile
+    (1, 256, 25, 25, 256, 3, 1, True, 0, False),       # + same-size residual
+    (2, 320, 9, 11, 200, 3, 1, False, 1, True),        # 45 K-steps: ksplit does not divide them; ragged cout tile; fp32 out
+])
+def test_conv2d_splitk_parity(cuda, dtype, n, cin, h, w, cout, k, stride, res, act, f32):
+    """Split-K launches of the register-staged kernel (round 5; torchvision ResNet-50 layer3 / layer4 and the FPN's extra levels as built at
+    cvpce/models/proposals.py:109-139) against the unsplit kernel (the same products, another fp32 summation order), against F.conv2d on
+    the same rounded operands, and against themselves: repeated launches on one workspace are bit-identical (the partial tiles are added
+    in split order)."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + h + k)
+    x = torch.randn(n, h, w, cin, generator=g).to(dtype)
+    wgt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(k * k * cin)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(wgt, bias, stride, k // 2, device=cuda, dtype=dtype)
+    xin = x.to(cuda)
+    ho, wo = pc.out_hw(h, w, 0)
+    r = torch.randn(n, ho, wo, cout, generator=g).to(dtype) if res else None
+    rin = r.to(cuda) if res else None
+    assert ops.splitk_factor(pc, ho, wo) == 4
+    ops.PROFILE = ops.ConvProfile()
+    try:
+        ys = [ops.conv2d(xin, pc, act=act, out_f32=f32, residual=rin).clone() for _ in range(3)]
+        assert 'split-K' in ops.PROFILE.layer_records[-1][0]                                   # the new path did run
+        ops.CONV_SPLITK = False
+        y2 = ops.conv2d(xin, pc, act=act, out_f32=f32, residual=rin)
+        assert 'split-K' not in ops.PROFILE.layer_records[-1][0]
+    finally:
+        ops.CONV_SPLITK = True
+        ops.PROFILE = None
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    y = ys[0]
+    assert y.dtype == (torch.float32 if f32 else dtype) and y.shape == y2.shape == (n, ho, wo, cout)
+    tol = 2e-5 if f32 else 2.0 ** (-7 if dtype == torch.bfloat16 else -10)                     # one storage ulp where a rounding tips
+    assert (y.float() - y2.float()).abs().max() <= tol * y2.float().abs().max() + 1e-6
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wgt.to(dtype).float(), bias, stride=stride, padding=k // 2)
+    if res:
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    if act:
+        ref = ref.relu()
+    assert rel_err(nchw(y.float()), ref) < (1e-4 if f32 else (6e-3 if dtype == torch.bfloat16 else 8e-4))
+    with pytest.raises(RuntimeError):                                                          # a workspace that is too small is refused
+        torch.ops.cvpce_amd.conv2d_splitk(xin, pc.weight, pc.bias, rin, torch.empty_like(y), pc.cout, k, k, stride, k // 2, ho, wo, pc.k_pad, pc.cout_pad,
+                                          act, int(f32), 0, 1 if res else 0, 4, torch.zeros(4096, dtype=torch.uint8, device=cuda))
+
+
 @pytest.mark.parametrize('n,use_map', [(3, False), (3, True), (90, True), (50, False)])
 def test_conv3x3_atlas_masked(cuda, n, use_map):
     """cvpce_conv3x3_halo_masked: two maps packed side by side with a one-pixel zero gap == the conv applied to each map
