@@ -976,13 +976,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // from LDS, write step kt + 1 (loaded one step ago) to the other LDS buffer.  Unrolled by two so that the register
     // slots are compile-time indices; past the last K-step the loads fetch zeros / the last weight step into buffers
     // nobody reads.
+    // (timing-only ablations of the register-staged kernel, tools/ablate.sh conv_igemm: CVPCE_DBG 1024 no global loads in the loop,
+    //  2048 no MFMAs, 4096 no barrier, 8192 no LDS stores)
 #define CVPCE_KSTEP(KT, SLOT)                                                                                  \
     {                                                                                                          \
-        CVPCE_LOAD_TILE((KT) + 2, (SLOT) ^ 1)                                                                  \
+        if constexpr (!(CVPCE_DBG & 1024)) { CVPCE_LOAD_TILE((KT) + 2, (SLOT) ^ 1) }                           \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        mfma_kstep<E, MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc); \
-        CVPCE_STORE_TILE(cur ^ 1, SLOT)                                                                        \
-        __syncthreads();                                                                                       \
+        if constexpr (!(CVPCE_DBG & 2048))                                                                     \
+            mfma_kstep<E, MT, NT, BK>(Ws + cur * TC * BK, Ps + cur * TP * BK, wc * (TC / WC), wp * (TP / WP), lane, acc); \
+        if constexpr (!(CVPCE_DBG & 8192)) { CVPCE_STORE_TILE(cur ^ 1, SLOT) }                                 \
+        if constexpr (!(CVPCE_DBG & 4096)) __syncthreads();                                                    \
         cur ^= 1;                                                                                              \
     }
     int kt = k_begin;
@@ -1022,31 +1025,46 @@ static int launch_conv(const ConvArgs& a0, hipStream_t stream) {
     return cvpce_check_launch();
 }
 
-// second launch of a split-K conv: workgroup = output tile, thread = the thread of conv_igemm_kernel<128, 128, 64, 2, 2> that held these
-// accumulators; the partial tiles are added in split order and go through the same epilogue
-template <typename E>
+// second launch of a split-K conv: workgroup = one 64 x 64 quarter of an output tile (the (mt, nt) pair of a wave's accumulators),
+// thread = the thread of conv_igemm_kernel<128, 128, 64, 2, 2> that held them; every partial of the thread is in flight before the
+// first add (one round trip to memory for the launch; as a loop over the splits it was four), the adds run in split order, the
+// epilogue is the unsplit kernel's
+template <typename E, int S>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
     constexpr int MT = 2, NT = 2, Q = MT * NT * 4, WP = 2;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wc = wid / WP, wp = wid % WP;
-    const int tile = blockIdx.x, ntile = a.tiles_c * a.tiles_p;
+    const int pair = blockIdx.x & 3, tile = blockIdx.x >> 2, ntile = a.tiles_c * a.tiles_p;
+    const int mt = pair >> 1, nt = pair & 1;
     const int tile_c = tile % a.tiles_c, tile_p = tile / a.tiles_c;
-    const f32x4* all = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)tile * Q) * 256 + tid;
-    f32x16 acc[MT][NT];
-    for (int sp = 0; sp < a.ksplit; ++sp) {
-        const f32x4* src = all + (size_t)sp * ntile * Q * 256;
+    const f32x4* all = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)tile * Q + pair * 4) * 256 + tid;
+    const int ns = S ? S : a.ksplit;
+    f32x16 acc[1][1];
+    if constexpr (S != 0) {
+        f32x4 v[S][4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int sp = 0; sp < S; ++sp)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int g = 0; g < 4; ++g) v[sp][g] = all[(size_t)sp * ntile * Q * 256 + g * 256];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = src[((mt * NT + nt) * 4 + g) * 256];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mt][nt][4 * g + j] = sp == 0 ? v[j] : acc[mt][nt][4 * g + j] + v[j];
-                }
+            for (int j = 0; j < 4; ++j) {
+                float x = v[0][g][j];
+#pragma unroll
+                for (int sp = 1; sp < S; ++sp) x += v[sp][g][j];
+                acc[0][0][4 * g + j] = x;
+            }
+    } else {
+        for (int sp = 0; sp < ns; ++sp)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = all[(size_t)sp * ntile * Q * 256 + g * 256];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0][0][4 * g + j] = sp == 0 ? v[j] : acc[0][0][4 * g + j] + v[j];
+            }
     }
-    conv_epilogue<E, MT, NT>(a, acc, tile_c * 128 + wc * 64, tile_p * 128 + wp * 64, lane);
+    conv_epilogue<E, 1, 1>(a, acc, tile_c * 128 + wc * 64 + mt * 32, tile_p * 128 + wp * 64 + nt * 32, lane);
 }
 
 // split-K launch pair of the 128 x 128 register-staged kernel
@@ -1065,7 +1083,9 @@ static int launch_conv_split(const ConvArgs& a0, int ksplit, void* workspace, si
     hipLaunchKernelGGL((conv_igemm_kernel<E, 128, 128, 64, 2, 2, true>), dim3((unsigned)(ntile * ksplit)), dim3(256), smem, stream, a);
     const int rc = cvpce_check_launch();
     if (rc != CVPCE_OK) return rc;
-    hipLaunchKernelGGL((conv_splitk_finish_kernel<E>), dim3((unsigned)ntile), dim3(256), 0, stream, a);
+    if (ksplit == 4) hipLaunchKernelGGL((conv_splitk_finish_kernel<E, 4>), dim3((unsigned)ntile * 4), dim3(256), 0, stream, a);
+    else if (ksplit == 2) hipLaunchKernelGGL((conv_splitk_finish_kernel<E, 2>), dim3((unsigned)ntile * 4), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_splitk_finish_kernel<E, 0>), dim3((unsigned)ntile * 4), dim3(256), 0, stream, a);
     return cvpce_check_launch();
 }
 
