@@ -53,6 +53,8 @@ SIGNATURES = {
                                           POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_crop_resize': (c_int, [_fp, _fp, _ip, c_int, _vp, c_int, c_int, c_int, c_int,
                                   POINTER(c_float), POINTER(c_float), _vp]),
+    'cvpce_crop_resize_content': (c_int, [_fp, _fp, _ip, c_int, _vp, c_int, c_int, c_int, c_int,
+                                          POINTER(c_float), POINTER(c_float), _ip, _vp]),
     'cvpce_pack_embed_input': (c_int, [_fp, _vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _vp]),
     'cvpce_crop_extents': (c_int, [_fp, _ip, c_int, c_int, c_int, c_int, c_int, _ip, _vp]),
     'cvpce_pad_extents': (c_int, [_fp, c_int, c_int, c_float, _ip, _vp]),

@@ -211,15 +211,28 @@ __global__ void crop_resize_kernel(const float* __restrict__ img, const float* _
 // Modes 1 / 2 for the embedder, TWO output pixels per thread: 24 independent gathers in flight per thread instead of 12 (the
 // one-pixel kernel is bound by load latency, not bandwidth) and one 16-byte store per thread in mode 2.  Same arithmetic,
 // expression for expression, as crop_resize_kernel.
+// ext (optional, cvpce_crop_resize_content): the crops' content extents -- rows / columns beyond them hold the pad constant and are
+// NOT written (their workgroups / threads leave at once): the work-list embedder reads them from the constant crop.
+// A workgroup is CROP2_ROWS output rows of one crop, one row per 128 threads (blockDim = (128, CROP2_ROWS)).  One row per workgroup
+// is the fastest form measured (per 200-crop launch of the bench's wide boxes, under the profiler: whole crops 64 us, content only
+// 48 us -- 60 % of its 51 200 workgroups leave at once); four rows per 512-thread workgroup 78 / 52 us; eight rows per THREAD, one
+// after the other, 104 / 92 us (a row's 24 gathers are the latency: they want many independent waves).
+#define CROP2_ROWS 1
 template <int MODE>
 __global__ void crop_resize2_kernel(const float* __restrict__ img, const float* __restrict__ boxes, const int* __restrict__ count,
                                     bf16_t* __restrict__ out, int H0, int W0, int S, float m0, float m1, float m2, float s0,
-                                    float s1, float s2) {
+                                    float s1, float s2, const int* __restrict__ ext) {
     const int p = blockIdx.z;
     if (count && p >= *count) return;
-    const int oy = blockIdx.y;
+    const int oy_first = blockIdx.y * CROP2_ROWS + threadIdx.y;
     const int ox0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (ox0 >= S) return;
+    int oy_end = oy_first + 1 < S ? oy_first + 1 : S;
+    if (ext) {
+        if (ox0 >= ext[2 * p + 1]) return;
+        oy_end = oy_end < ext[2 * p] ? oy_end : ext[2 * p];
+    }
+    if (oy_first >= oy_end) return;
     const float* b = boxes + (size_t)p * 4;
     long long x1 = (long long)b[0], y1 = (long long)b[1], x2 = (long long)b[2], y2 = (long long)b[3];
     x1 = x1 < 0 ? 0 : (x1 > W0 ? W0 : x1);
@@ -230,78 +243,99 @@ __global__ void crop_resize2_kernel(const float* __restrict__ img, const float* 
     if (cw < 0) cw = 0;
     if (ch < 0) ch = 0;
     const int larger = cw > ch ? cw : ch;
-    float v[2][3] = {{0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}};
+    const float sc = (float)larger / (float)S;
+    int xx0[2] = {0, 0}, xx1[2] = {0, 0};
+    float lx0[2] = {0.f, 0.f}, lx1[2] = {0.f, 0.f};
     if (larger > 0) {
-        const float sc = (float)larger / (float)S;
-        int yy0, yy1, xx0[2], xx1[2];
-        float ly0, ly1, lx0[2], lx1[2];
-        src_index(sc, oy, larger, yy0, yy1, ly0, ly1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) src_index(sc, ox0 + u, larger, xx0[u], xx1[u], lx0[u], lx1[u]);
-        float t[2][3][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* pl = img + (size_t)c * H0 * W0;
-                auto at = [&](int yy, int xx) -> float {
-                    return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
-                };
-                t[u][c][0] = at(yy0, xx0[u]); t[u][c][1] = at(yy0, xx1[u]); t[u][c][2] = at(yy1, xx0[u]); t[u][c][3] = at(yy1, xx1[u]);
-            }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (yy0 < ch && xx0[u] < cw) {                   // else: all four taps are padding -> exactly 0.5 (see crop_resize_kernel)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    v[u][c] = ly0 * (lx0[u] * t[u][c][0] + lx1[u] * t[u][c][1]) + ly1 * (lx0[u] * t[u][c][2] + lx1[u] * t[u][c][3]);
-            }
     }
     const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
-    bf16_t o[2][4];
+    for (int oy = oy_first; oy < oy_end; ++oy) {
+        float v[2][3] = {{0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}};
+        if (larger > 0) {
+            int yy0, yy1;
+            float ly0, ly1;
+            src_index(sc, oy, larger, yy0, yy1, ly0, ly1);
+            float t[2][3][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[u][c] = f32_to_bf16((v[u][c] * 2.f - 1.f - mean[c]) / stdv[c]);
-        o[u][3] = (bf16_t)0.f;
-    }
-    const size_t pix = ((size_t)p * S + oy) * S + ox0;
-    if (MODE == 2) {
-        const bf16x8 w = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
-        if (ox0 + 1 < S) *reinterpret_cast<bf16x8*>(out + pix * 4) = w;
-        else *reinterpret_cast<bf16x4*>(out + pix * 4) = bf16x4{o[0][0], o[0][1], o[0][2], o[0][3]};
-    } else {
+                for (int c = 0; c < 3; ++c) {
+                    const float* pl = img + (size_t)c * H0 * W0;
+                    auto at = [&](int yy, int xx) -> float {
+                        return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
+                    };
+                    t[u][c][0] = at(yy0, xx0[u]); t[u][c][1] = at(yy0, xx1[u]); t[u][c][2] = at(yy1, xx0[u]); t[u][c][3] = at(yy1, xx1[u]);
+                }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (ox0 + u < S) {
-                const bf16x8 w = {o[u][0], o[u][1], o[u][2], (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                *reinterpret_cast<bf16x8*>(out + (pix + u) * 8) = w;
-            }
+            for (int u = 0; u < 2; ++u)
+                if (yy0 < ch && xx0[u] < cw) {               // else: all four taps are padding -> exactly 0.5 (see crop_resize_kernel)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        v[u][c] = ly0 * (lx0[u] * t[u][c][0] + lx1[u] * t[u][c][1]) + ly1 * (lx0[u] * t[u][c][2] + lx1[u] * t[u][c][3]);
+                }
+        }
+        bf16_t o[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[u][c] = f32_to_bf16((v[u][c] * 2.f - 1.f - mean[c]) / stdv[c]);
+            o[u][3] = (bf16_t)0.f;
+        }
+        const size_t pix = ((size_t)p * S + oy) * S + ox0;
+        if (MODE == 2) {
+            const bf16x8 w = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+            if (ox0 + 1 < S) *reinterpret_cast<bf16x8*>(out + pix * 4) = w;
+            else *reinterpret_cast<bf16x4*>(out + pix * 4) = bf16x4{o[0][0], o[0][1], o[0][2], o[0][3]};
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ox0 + u < S) {
+                    const bf16x8 w = {o[u][0], o[u][1], o[u][2], (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                    *reinterpret_cast<bf16x8*>(out + (pix + u) * 8) = w;
+                }
+        }
     }
 }
 
-extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
-                                 int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream) {
+static int crop_resize_launch(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
+                             int H0, int W0, int S, int mode, const float* mean3, const float* std3, const int* ext, void* stream) {
     if (!img || !boxes || !out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
     if (mode < 0 || mode > 2 || (mode != 0 && (!mean3 || !std3))) return CVPCE_ERR_ARG;
+    if (ext && (mode == 0 || S % 2 != 0)) return CVPCE_ERR_ARG;
     if (max_boxes <= 0) return CVPCE_OK;
     if (max_boxes > 65535) return CVPCE_ERR_ARG;
     dim3 grid((S + 127) / 128, S, max_boxes);
     float m[3] = {0, 0, 0}, s[3] = {1, 1, 1};
     if (mode != 0) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; s[i] = std3[i]; }
     if (mode != 0 && S % 2 == 0) {
-        dim3 grid2((S / 2 + 127) / 128, S, max_boxes);
+        dim3 grid2((S / 2 + 127) / 128, (S + CROP2_ROWS - 1) / CROP2_ROWS, max_boxes);
         if (mode == 2)
-            hipLaunchKernelGGL(crop_resize2_kernel<2>, grid2, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
-                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2]);
+            hipLaunchKernelGGL(crop_resize2_kernel<2>, grid2, dim3(128, CROP2_ROWS), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
+                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2], ext);
         else
-            hipLaunchKernelGGL(crop_resize2_kernel<1>, grid2, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
-                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2]);
+            hipLaunchKernelGGL(crop_resize2_kernel<1>, grid2, dim3(128, CROP2_ROWS), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
+                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2], ext);
         return cvpce_check_launch();
     }
     hipLaunchKernelGGL(crop_resize_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, out, H0, W0,
                        S, mode, m[0], m[1], m[2], s[0], s[1], s[2]);
     return cvpce_check_launch();
+}
+
+extern "C" int cvpce_crop_resize(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
+                                 int H0, int W0, int S, int mode, const float* mean3, const float* std3, void* stream) {
+    return crop_resize_launch(img, boxes, count_dev, max_boxes, out, H0, W0, S, mode, mean3, std3, nullptr, stream);
+}
+
+// The crops' CONTENT only (modes 1 / 2, even S): pixels with oy >= ext[p].rows or ox >= ext[p].cols (cvpce_crop_extents of the same
+// boxes, launched before this) are left unwritten -- valid input only for the work-list embedder, which never reads them.
+extern "C" int cvpce_crop_resize_content(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
+                                         int H0, int W0, int S, int mode, const float* mean3, const float* std3, const int* ext,
+                                         void* stream) {
+    if (!ext) return CVPCE_ERR_ARG;
+    return crop_resize_launch(img, boxes, count_dev, max_boxes, out, H0, W0, S, mode, mean3, std3, ext, stream);
 }
 
 // Content extent of every crop at the crop resolution S (the embedder's constant-padding tile skipping, skiplist.hip):

@@ -137,12 +137,17 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
             tx = r - ty * a.tiles_x;
         }
     };
-    auto load_patch = [&](unsigned item) {
+    // LIST: `ext` = (ey << 12) | ex, the crop's content extent from the entry's high word -- a pixel with y >= ey or x >= ex is the pad
+    // constant and is read from the constant crop (the crop kernel may not have written it: cvpce_crop_resize_content)
+    auto load_patch = [&](unsigned item, unsigned ext) {
         int n, ty, tx;
         decode(item, n, ty, tx);
         const bf16_t* img = a.in + (size_t)n * a.H * a.W * a.cstride;
+        int ey = a.H, ex = a.W;
         if constexpr (LIST) {
             if (n == a.N - 1) img = a.const_in;
+            ey = (int)((ext >> 12) & 0xFFFu);
+            ex = (int)(ext & 0xFFFu);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -151,8 +156,10 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
             if (p < S2_P0 * S2_P0) {
                 const int py = p / S2_P0, px = p - py * S2_P0;
                 const int y = ty * S2_T - 2 + py, x = tx * S2_T - 2 + px;
+                const bf16_t* src = img;
+                if constexpr (LIST) src = (y >= ey || x >= ex) ? a.const_in : img;
                 if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                    v = *reinterpret_cast<const unsigned long long*>(img + ((size_t)y * a.W + x) * a.cstride);
+                    v = *reinterpret_cast<const unsigned long long*>(src + ((size_t)y * a.W + x) * a.cstride);
             }
             preg[k] = v;
         }
@@ -175,8 +182,13 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
         if constexpr (LIST) return t < ntiles ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a.list[t]) : 0u;
         return (unsigned)t;
     };
+    auto ext_at = [&](int t) -> unsigned {
+        if constexpr (LIST) return t < ntiles ? (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a.list[t] >> 32)) : 0u;
+        return 0u;
+    };
     unsigned it_cur = item_at(tile), it_next = item_at(tile + stride);
-    load_patch(it_cur);
+    unsigned ex_next = ext_at(tile + stride);
+    load_patch(it_cur, ext_at(tile));
     store_patch();
     team_barrier(cnt_addr, bar_target, lane);
 
@@ -216,9 +228,10 @@ __global__ __launch_bounds__(512, 2) void vgg_stem2_kernel(Stem2Args a) {
         int n, ty, tx;
         decode(it_cur, n, ty, tx);
         const int next = tile + stride;
-        if (next < ntiles) load_patch(it_next);         // global loads in flight under the conv1_1 phase
+        if (next < ntiles) load_patch(it_next, ex_next);   // global loads in flight under the conv1_1 phase
         it_cur = it_next;
         it_next = item_at(next + stride);
+        ex_next = ext_at(next + stride);
         const bool border = ty == 0 || tx == 0 || ty == a.tiles_y - 1 || tx == a.tiles_x - 1;
 
         // ================= phase 1: conv1_1 on the 18x18 patch -> A1 =================

@@ -274,7 +274,12 @@ class MACVGGEngine:
         run(big, ext, early, nl, N + 1)
         return desc[:N]
 
-    def embed_packed(self, x, eps=1e-8, want_bf16=False, batch=None, ext=None, const_in=None):
+    def will_skip(self, size):
+        """Whether `embed_packed(x, ext=..., const_in=...)` on (B, size, size, c) crops runs the work-list schedule (the condition
+        `embed_packed` evaluates: the module switch, the fused stem, a schedule for this size)."""
+        return bool(SKIP_PADDING and self.stem is not None and size * size <= INPUT_SIZE * INPUT_SIZE and self.skip_plan(size) is not None)
+
+    def embed_packed(self, x, eps=1e-8, want_bf16=False, batch=None, ext=None, const_in=None, partial=False):
         """x: (B,256,256,8) bf16, already normalised -> (B,1024) f32 unit-norm [, bf16 copy].
         batch: crops per pass of the kernel schedule (default MAX_EMBED_BATCH; a host that runs on fewer CUs passes that
         CU count so that the persistent kernels' tile counts stay whole multiples of their grid).
@@ -285,6 +290,8 @@ class MACVGGEngine:
         step = batch or (FUSED_EMBED_BATCH if fused else MAX_EMBED_BATCH)
         plan = self.plan + [('desc', None)]            # the second descriptor: amax of the last map (classification.py:48-49)
         sched = self.skip_plan(x.shape[1]) if (SKIP_PADDING and ext is not None and const_in is not None and fused and x.shape[1] == x.shape[2]) else None
+        if partial and sched is None:
+            raise RuntimeError('embed_packed: crops that hold their content only (ops.crop_resize content_ext) need the work-list schedule')
         if sched is not None and x.shape[0]:
             # (the late layers' tensors: 64 x 64 x 256 per crop -> at most LATE_EMBED_MAX crops per call under the 32-bit tensor limits)
             for s, e in _passes(x.shape[0], LATE_EMBED_MAX, LATE_EMBED_MAX):

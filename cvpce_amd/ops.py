@@ -755,9 +755,11 @@ def gln_transform_batch(images, batch, sizes, mean, std):
 MAX_CROPS_PER_LAUNCH = 65535
 
 
-def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, out=None):
+def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, out=None, content_ext=None):
     """img (3,H0,W0) f32, boxes (P,4) f32 xyxy (device) -> (P,3,S,S) f32 [mode 0] | (P,S,S,8) bf16 [mode 1] | (P,S,S,4) bf16
-    [mode 2: the 8-byte pixels the fused VGG stem reads; half the bytes of mode 1]."""
+    [mode 2: the 8-byte pixels the fused VGG stem reads; half the bytes of mode 1].
+    content_ext (P,2) int32 (`crop_extents` of the same boxes; modes 1 / 2): only the crops' CONTENT is written -- the constant padding
+    beyond the extents stays unwritten, which only the work-list embedder may be given (it reads it from the constant crop)."""
     _need_cuda(img, boxes)
     assert img.dtype == torch.float32 and img.is_contiguous()
     boxes = boxes.to(torch.float32).contiguous()
@@ -778,14 +780,23 @@ def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, o
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        T.crop_resize(img, boxes[start:start + nb], cnt, out[start:start + nb], size, mode, m, s)
+        if content_ext is not None:
+            assert mode in (1, 2) and size % 2 == 0
+            T.crop_resize_content(img, boxes[start:start + nb], cnt, out[start:start + nb], size, mode, m, s, content_ext[start:start + nb])
+        else:
+            T.crop_resize(img, boxes[start:start + nb], cnt, out[start:start + nb], size, mode, m, s)
         if prof is not None:
             e1.record()
-            # algorithmic bytes: every source pixel of every (valid) box once (3 planes of f32) + the crops written
+            # algorithmic bytes: every source pixel of every (valid) box once (3 planes of f32) + the crop pixels written
             v = nb if cnt is None else int(cnt.reshape(-1)[0])
             b = boxes[start:start + v].to(torch.long)
             area = int(((b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)).sum())
-            prof.byte_records.append(('crop_resize_kernel', area * 3 * 4 + v * out[0].numel() * out.element_size(), e0, e1))
+            if content_ext is not None:
+                e = content_ext[start:start + v].to(torch.long)
+                written = int((e[:, 0] * e[:, 1]).sum()) * out.shape[-1] * out.element_size()
+            else:
+                written = v * out[0].numel() * out.element_size()
+            prof.byte_records.append(('crop_resize_kernel', area * 3 * 4 + written, e0, e1))
     return out
 
 

@@ -8,6 +8,8 @@ Differences from the reference, all on the device-boundary side:
   * degenerate (zero-area after `.to(long)`) boxes make the reference raise inside
     `resize_for_classification`; here they are dropped (documented divergence).
 """
+import os
+
 import torch
 
 from . import datautils, ops
@@ -333,6 +335,9 @@ class PlanogramEvaluator:
             yield from flush()
 
 
+CROP_CONTENT_ONLY = os.environ.get('CVPCE_CROP_CONTENT', '1') != '0'   # A/B switch: the crop kernel leaves the constant padding unwritten for the work-list embedder
+
+
 class BatchedPipeline:
     """detect -> RoI crop -> embed -> match for a batch of shelf images, device-resident end to end.
 
@@ -347,10 +352,13 @@ class BatchedPipeline:
         self.classifier = classifier
         self.confidence_threshold = confidence_threshold
 
-    def _crops(self, images, det_out):
+    def _crops(self, images, det_out, content_only=True):
         """RoI crops of every image's confident boxes, launched WITHOUT knowing the counts on the host: the crop kernel reads
         the boxes and the confidence-prefix count from device memory and skips the slots beyond it.
-        -> (crops, their content extents | None, the encoder's all-padding crop | None)."""
+        -> (crops, their content extents | None, the encoder's all-padding crop | None, partial).
+        partial (content_only and an encoder that runs the work-list schedule): only the crops' content was written -- the constant
+        padding beyond the extents is never read by that schedule (it reads the constant crop instead), so it is not produced either;
+        `embed_packed(..., partial=True)` refuses to run any other schedule on such crops."""
         boxes, scores, labels, count, conf_count, gauss = det_out
         eng = self.detector.engine()
         emb_eng = self.classifier.encoder.engine()
@@ -366,14 +374,15 @@ class BatchedPipeline:
         skip = hasattr(emb_eng, 'skip_plan') and emb_eng.skip_plan(size) is not None
         ext = torch.empty((n * dpi, 2), dtype=torch.int32, device=eng.device) if skip else None
         same_size = all(img.shape == images[0].shape for img in images)
-        for i, img in enumerate(images):
-            ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=mean, std=std, count=conf_count[i:i + 1],
-                            out=crops[i * dpi:(i + 1) * dpi])
-            if skip and not same_size:
-                ops.crop_extents(boxes[i], conf_count[i:i + 1], img.shape[1], img.shape[2], size, out=ext[i * dpi:(i + 1) * dpi])
+        partial = bool(content_only and skip and CROP_CONTENT_ONLY and emb_eng.will_skip(size))
         if skip and same_size:                   # (images of one size: the extents of the whole batch in one launch)
             ops.crop_extents(boxes.reshape(n * dpi, 4), conf_count, images[0].shape[1], images[0].shape[2], size, out=ext, per_image=dpi)
-        return crops, ext, (emb_eng.const_crop(mean, std, crops.shape[3], size) if skip else None)
+        for i, img in enumerate(images):
+            if skip and not same_size:
+                ops.crop_extents(boxes[i], conf_count[i:i + 1], img.shape[1], img.shape[2], size, out=ext[i * dpi:(i + 1) * dpi])
+            ops.crop_resize(img, boxes[i], size, mode=2 if narrow else 1, mean=mean, std=std, count=conf_count[i:i + 1],
+                            out=crops[i * dpi:(i + 1) * dpi], content_ext=ext[i * dpi:(i + 1) * dpi] if partial else None)
+        return crops, ext, (emb_eng.const_crop(mean, std, crops.shape[3], size) if skip else None), partial
 
     def _select(self, crops, counts, ext=None):
         """The embedder only runs over the valid crops (compaction = a gather of row indices; their extents go along)."""
@@ -390,7 +399,7 @@ class BatchedPipeline:
 
     def _crop_embed_match(self, images, det_out, counts, embed_batch=None):
         """(kept for the dev tools) crops + selection with counts already on the host."""
-        crops, ext, const_in = self._crops(images, det_out)
+        crops, ext, const_in, _ = self._crops(images, det_out, content_only=False)     # (whole crops: the tools embed them without lists too)
         valid, sel, ext = self._select(crops, counts, ext)
         return crops, valid, sel
 
@@ -446,13 +455,13 @@ class BatchedPipeline:
         pin[n].copy_(det_out[4], non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
-        crops, ext, const_in = self._crops(images, det_out)
+        crops, ext, const_in, partial = self._crops(images, det_out)
         copied.synchronize()
         counts = pin[n].tolist()
         valid, sel, ext = self._select(crops, counts, ext)
         t2 = mark()
         if ext is not None:         # (an encoder with the work-list schedule: the tiles in the crops' constant padding are skipped)
-            emb = self.classifier.encoder.engine().embed_packed(valid, ext=ext, const_in=const_in)
+            emb = self.classifier.encoder.engine().embed_packed(valid, ext=ext, const_in=const_in, partial=partial)
         else:
             emb = self.classifier.encoder.engine().embed_packed(valid)
         t3 = mark()

@@ -219,6 +219,14 @@ def _crop_resize(img, boxes, count, out, size, mode, mean, std):
                                 _stream()), 'crop_resize')
 
 
+@_op('crop_resize_content(Tensor img, Tensor boxes, Tensor? count, Tensor(a!) out, int size, int mode, float[] mean, float[] std, Tensor ext) -> ()')
+def _crop_resize_content(img, boxes, count, out, size, mode, mean, std, ext):
+    if ext.dtype != torch.int32 or not ext.is_contiguous() or ext.shape != (boxes.shape[0], 2):
+        raise RuntimeError('crop_resize_content: ext must be a contiguous (P,2) int32 tensor')
+    check(lib.cvpce_crop_resize_content(_p(img), _p(boxes), _p(count), boxes.shape[0], _p(out), img.shape[1], img.shape[2], size, mode,
+                                        _lib.float3(mean), _lib.float3(std), _p(ext), _stream()), 'crop_resize_content')
+
+
 @_op('crop_extents(Tensor boxes, Tensor? count, int per_image, int h0, int w0, int size, Tensor(a!) ext) -> ()')
 def _crop_extents(boxes, count, per_image, h0, w0, size, ext):
     if boxes.dtype != torch.float32 or not boxes.is_contiguous() or ext.dtype != torch.int32 or not ext.is_contiguous() or ext.numel() < 2 * boxes.shape[0] \

@@ -224,6 +224,11 @@ int cvpce_pack_embed_input(const float* in, void* out_nhwc8, int B, int S, int t
  * image -- the whole batch in one launch. */
 int cvpce_crop_extents(const float* boxes, const int* count_dev, int max_boxes, int boxes_per_image, int H0, int W0, int S,
                        int* ext_out, void* stream);
+/* cvpce_crop_resize (modes 1 / 2, even S) writing the crops' CONTENT only: pixels with oy >= ext[p].rows or ox >= ext[p].cols
+ * (`ext` = cvpce_crop_extents of the same boxes, launched before) are left UNWRITTEN.  Input for the *_list entry points only,
+ * which read those pixels from the constant crop (ii above); the written pixels are bit-identical to cvpce_crop_resize's. */
+int cvpce_crop_resize_content(const float* img, const float* boxes, const int* count_dev, int max_boxes, void* out,
+                              int H0, int W0, int S, int mode, const float* mean3, const float* std3, const int* ext, void* stream);
 /* The same extents read off crops that already exist as (B,3,S,S) f32 tensors (the input of Classifier.classify,
  * production.py:57-74): every pixel with y >= rows or x >= cols equals `pad` (0.5) in all three channels.  Data-driven: a tensor
  * without constant borders gets (S, S). */

@@ -50,7 +50,7 @@ def test_torch_ops_registered_for_the_gpu_only():
         assert base in declared or base + '_bf16' in declared, t
     declared -= twins
     # (the two 3x3 halo entry points share one op: Cout <= 128 is forwarded to the wide-tile kernel inside the library)
-    assert len(torch_ops.NAMES) == len(declared) == 37   # (round 5: + the head's thin-output 3x3, the fragment-major bottleneck, the split-K form of the register-staged conv) (two halo entry points share an op; atlas_copy has two; round 4: the seven work-list / extent / MAC-start entry points, the Gaussian subnet's tail and its thin 3x3 layers; round 5: the matcher's one-launch form and its state initialiser)
+    assert len(torch_ops.NAMES) == len(declared) == 38   # (round 5: + the head's thin-output 3x3, the fragment-major bottleneck, the split-K form of the register-staged conv, the content-only crop) (two halo entry points share an op; atlas_copy has two; round 4: the seven work-list / extent / MAC-start entry points, the Gaussian subnet's tail and its thin 3x3 layers; round 5: the matcher's one-launch form and its state initialiser)
     for name in torch_ops.NAMES:
         op = getattr(torch.ops.cvpce_amd, name)
         assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'cvpce_amd::{name}', 'CPU')

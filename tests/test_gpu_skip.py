@@ -230,6 +230,85 @@ def test_multi_pass_and_all_padding(cuda, skip_rows):
         C.LATE_EMBED_MAX = old
 
 
+def test_content_only_crops(cuda):
+    """`ops.crop_resize(..., content_ext=ext)` (cvpce_crop_resize_content, round 5) writes the crops' content and nothing else: inside
+    the extents the pixels are the full crop's bit for bit, outside them the buffer keeps what it held (NaNs here); the work-list
+    embedder returns the embeddings of the full crops from it (it reads the padding from the constant crop: no NaN reaches an MFMA),
+    and any other schedule refuses such crops.  `datautils.py:232-239` is the padding this rests on."""
+    from cvpce_amd import ops, synthetic
+    from cvpce_amd.models import classification as C
+    enc = synthetic.synthetic_macvgg(seed=1).cuda()
+    eng = enc.engine()
+    h0, w0 = 600, 800
+    img = torch.rand(3, h0, w0, generator=torch.Generator().manual_seed(3)).cuda()
+    g = torch.Generator().manual_seed(9)
+    n = 40
+    x1 = torch.rand(n, generator=g) * 400; y1 = torch.rand(n, generator=g) * 300
+    wh = 40 + torch.rand(n, 2, generator=g) * 220                                        # wide, tall and near-square boxes
+    boxes = torch.stack((x1, y1, x1 + wh[:, 0], y1 + wh[:, 1]), dim=1)
+    boxes[5] = torch.tensor([10.0, 10.0, 10.5, 90.0])                                     # zero width: nothing is written at all
+    boxes[6] = torch.tensor([700.0, 500.0, 900.0, 700.0])                                 # clipped at the image border
+    boxes = boxes.cuda()
+    count = torch.tensor([n - 3], dtype=torch.int32, device='cuda')                        # the last three slots are beyond the count
+    full = ops.crop_resize(img, boxes, S, mode=2, mean=C.TANH_MEAN, std=C.TANH_STD, count=count)
+    ext = ops.crop_extents(boxes, count, h0, w0, S)
+    nan = torch.full((n, S, S, 4), float('nan'), dtype=torch.bfloat16, device='cuda')
+    part = ops.crop_resize(img, boxes, S, mode=2, mean=C.TANH_MEAN, std=C.TANH_STD, count=count, out=nan.clone(), content_ext=ext)
+    torch.cuda.synchronize()
+    e = ext.cpu()
+    yy = torch.arange(S).view(1, S, 1); xx = torch.arange(S).view(1, 1, S)
+    # (a thread writes two pixels: a content row may run one pixel past an odd column extent)
+    inside = ((yy < e[:, 0].view(-1, 1, 1)) & (xx < e[:, 1].view(-1, 1, 1))).cuda()
+    inside[n - 3:] = False
+    outside = ((yy >= e[:, 0].view(-1, 1, 1)) | (xx >= (e[:, 1] + (e[:, 1] & 1)).view(-1, 1, 1))).cuda()
+    outside[n - 3:] = True
+    pv, fv = part.view(torch.int16), full.view(torch.int16)
+    assert torch.equal(pv[inside], fv[inside])
+    assert bool(torch.isnan(part[outside].float()).all())
+    assert int(inside[5].sum()) == 0 and 0 < int(inside.sum()) < int((n - 3) * S * S * 0.8)
+    const = eng.const_crop(C.TANH_MEAN, C.TANH_STD, 4, S)
+    v = n - 3
+    plain = eng.embed_packed(full[:v])
+    assert torch.equal(eng.embed_packed(part[:v], ext=ext[:v], const_in=const, partial=True), plain)
+    assert bool(torch.isfinite(plain).all())
+    with pytest.raises(RuntimeError, match='work-list'):
+        eng.embed_packed(part[:v], partial=True)                                          # no extents: the plain schedule would read the NaNs
+    C.SKIP_PADDING = False
+    try:
+        assert not eng.will_skip(S)
+        with pytest.raises(RuntimeError, match='work-list'):
+            eng.embed_packed(part[:v], ext=ext[:v], const_in=const, partial=True)
+    finally:
+        C.SKIP_PADDING = True
+    assert eng.will_skip(S)
+    with pytest.raises(RuntimeError):                                                      # mode 0 (f32 planes) has no content-only form
+        torch.ops.cvpce_amd.crop_resize_content(img, boxes, None, torch.empty(n, 3, S, S, device='cuda'), S, 0, list(C.TANH_MEAN), list(C.TANH_STD), ext)
+
+
+def test_pipeline_content_only_crops_switch(cuda):
+    """BatchedPipeline with the crop kernel writing content only (default) and whole crops: the same results bit for bit, for images of
+    one size (extents of the batch in one launch) and of different sizes (per image)."""
+    from cvpce_amd import production, synthetic
+    dev = torch.device('cuda:0')
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=40).to(dev)
+    enc = synthetic.synthetic_macvgg(seed=1).to(dev)
+    clf = production.Classifier(enc, synthetic.TensorGallery(synthetic.gallery_images(32, seed=100)), device=dev, emb_device=dev, batch_size=16,
+                                match_dtype=torch.bfloat16)
+    pipe = production.BatchedPipeline(det, clf, 0.5)
+    for sizes in (((640, 768), (640, 768)), ((640, 768), (512, 704))):
+        imgs = [synthetic.shelf_image(50 + i, h, w).to(dev) for i, (h, w) in enumerate(sizes)]
+        assert production.CROP_CONTENT_ONLY
+        on = pipe.run(imgs)
+        production.CROP_CONTENT_ONLY = False
+        try:
+            off = pipe.run(imgs)
+        finally:
+            production.CROP_CONTENT_ONLY = True
+        assert int(on['count'].sum()) > 0
+        for k in ('boxes', 'scores', 'indices', 'embeddings', 'count'):
+            assert torch.equal(on[k], off[k]), k
+
+
 def test_pipeline_results_identical_with_and_without_skipping(cuda):
     from cvpce_amd import production, synthetic
     from cvpce_amd.models import classification as C
