@@ -216,25 +216,43 @@ __global__ void crop_resize_kernel(const float* __restrict__ img, const float* _
 // A workgroup is CROP2_ROWS output rows of one crop, one row per 128 threads (blockDim = (128, CROP2_ROWS)).  One row per workgroup
 // is the fastest form measured (per 200-crop launch of the bench's wide boxes, under the profiler: whole crops 64 us, content only
 // 48 us -- 60 % of its 51 200 workgroups leave at once); four rows per 512-thread workgroup 78 / 52 us; eight rows per THREAD, one
-// after the other, 104 / 92 us (a row's 24 gathers are the latency: they want many independent waves).
+// after the other, 104 / 92 us (a row's 24 gathers are the latency: they want many independent waves).  What bounds the content-only
+// form is VALU issue: ~700 instructions per wave (index arithmetic, six IEEE divisions, the box decode) x 40 000 live waves x 4 clocks
+// on 1 024 SIMDs = 52 us; fetching count / extents / box in one round trip, branch-free gathers and two rows per workgroup each
+// changed nothing (44.0 / 44.1 / 43.3 us).
 #define CROP2_ROWS 1
 template <int MODE>
 __global__ void crop_resize2_kernel(const float* __restrict__ img, const float* __restrict__ boxes, const int* __restrict__ count,
                                     bf16_t* __restrict__ out, int H0, int W0, int S, float m0, float m1, float m2, float s0,
-                                    float s1, float s2, const int* __restrict__ ext) {
-    const int p = blockIdx.z;
-    if (count && p >= *count) return;
-    const int oy_first = blockIdx.y * CROP2_ROWS + threadIdx.y;
+                                    float s1, float s2, const int* __restrict__ ext, int nbox) {
+    // XCD-aware order (one workgroup per row: gridDim.x == 1): workgroups are dealt to the 8 XCDs round-robin in launch order, and
+    // neighbouring output rows read the same source rows -- all rows of a crop go to ONE XCD's L2 (crop = 8 * (idx / rows) + xcd);
+    // in launch order every source row was fetched into several L2s (PMC: 1.58 x the algorithmic bytes)
+    int p = blockIdx.z, by = blockIdx.y;
+    if (gridDim.x == 1) {
+        const int L = (int)(blockIdx.y + gridDim.y * blockIdx.z), xcd = L & 7, idx = L >> 3;
+        p = (idx / (int)gridDim.y) * 8 + xcd;
+        by = idx % (int)gridDim.y;
+    }
+    if (p >= nbox) return;                                 // (the grid's z extent is rounded up to a multiple of 8)
+    // the count, the crop's extents and its box are fetched TOGETHER, before the first of them is looked at: as `if (p >= *count)
+    // return; if (oy >= ext[..]) return; b = boxes[..]` they were three dependent round trips at the head of every wave's life
+    const float* b = boxes + (size_t)p * 4;
+    const int* cptr = count ? count : reinterpret_cast<const int*>(b);
+    const int* eptr = ext ? ext + 2 * p : reinterpret_cast<const int*>(b);
+    const int n_valid = *cptr, e_rows = eptr[0], e_cols = eptr[1];
+    const float bx1 = b[0], by1 = b[1], bx2 = b[2], by2 = b[3];
+    if (count && p >= n_valid) return;
+    const int oy_first = by * CROP2_ROWS + threadIdx.y;
     const int ox0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (ox0 >= S) return;
     int oy_end = oy_first + 1 < S ? oy_first + 1 : S;
     if (ext) {
-        if (ox0 >= ext[2 * p + 1]) return;
-        oy_end = oy_end < ext[2 * p] ? oy_end : ext[2 * p];
+        if (ox0 >= e_cols) return;
+        oy_end = oy_end < e_rows ? oy_end : e_rows;
     }
     if (oy_first >= oy_end) return;
-    const float* b = boxes + (size_t)p * 4;
-    long long x1 = (long long)b[0], y1 = (long long)b[1], x2 = (long long)b[2], y2 = (long long)b[3];
+    long long x1 = (long long)bx1, y1 = (long long)by1, x2 = (long long)bx2, y2 = (long long)by2;
     x1 = x1 < 0 ? 0 : (x1 > W0 ? W0 : x1);
     x2 = x2 < 0 ? 0 : (x2 > W0 ? W0 : x2);
     y1 = y1 < 0 ? 0 : (y1 > H0 ? H0 : y1);
@@ -257,17 +275,27 @@ __global__ void crop_resize2_kernel(const float* __restrict__ img, const float* 
             int yy0, yy1;
             float ly0, ly1;
             src_index(sc, oy, larger, yy0, yy1, ly0, ly1);
+            // the 24 taps: every load is issued (at an address clamped into the plane), padding taps are replaced afterwards -- behind
+            // `tap inside ? load : 0.5` branches the loads went out one exec-mask region at a time
             float t[2][3][4];
+            const int plane = H0 * W0;                       // (< 2^31: checked on the host)
+            const int yo[2] = {yy0, yy1};
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                const int xo[2] = {xx0[u], xx1[u]};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float* pl = img + (size_t)c * H0 * W0;
-                    auto at = [&](int yy, int xx) -> float {
-                        return (yy < ch && xx < cw) ? pl[(size_t)(y1 + yy) * W0 + (x1 + xx)] : 0.5f;
-                    };
-                    t[u][c][0] = at(yy0, xx0[u]); t[u][c][1] = at(yy0, xx1[u]); t[u][c][2] = at(yy1, xx0[u]); t[u][c][3] = at(yy1, xx1[u]);
+                for (int k = 0; k < 4; ++k) {
+                    const int yy = yo[k >> 1], xx = xo[k & 1];
+                    const bool in = yy < ch && xx < cw;
+                    int off = ((int)y1 + yy) * W0 + ((int)x1 + xx);
+                    off = in ? off : 0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float raw = img[(size_t)c * plane + off];
+                        t[u][c][k] = in ? raw : 0.5f;
+                    }
                 }
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (yy0 < ch && xx0[u] < cw) {               // else: all four taps are padding -> exactly 0.5 (see crop_resize_kernel)
@@ -304,19 +332,20 @@ static int crop_resize_launch(const float* img, const float* boxes, const int* c
     if (!img || !boxes || !out || S <= 0 || H0 <= 0 || W0 <= 0) return CVPCE_ERR_ARG;
     if (mode < 0 || mode > 2 || (mode != 0 && (!mean3 || !std3))) return CVPCE_ERR_ARG;
     if (ext && (mode == 0 || S % 2 != 0)) return CVPCE_ERR_ARG;
+    if ((long long)H0 * W0 >= (1LL << 31)) return CVPCE_ERR_ARG;        // (32-bit pixel offsets within a plane)
     if (max_boxes <= 0) return CVPCE_OK;
-    if (max_boxes > 65535) return CVPCE_ERR_ARG;
+    if (max_boxes > 65528) return CVPCE_ERR_ARG;          // (grid z, rounded up to a multiple of 8)
     dim3 grid((S + 127) / 128, S, max_boxes);
     float m[3] = {0, 0, 0}, s[3] = {1, 1, 1};
     if (mode != 0) for (int i = 0; i < 3; ++i) { m[i] = mean3[i]; s[i] = std3[i]; }
     if (mode != 0 && S % 2 == 0) {
-        dim3 grid2((S / 2 + 127) / 128, (S + CROP2_ROWS - 1) / CROP2_ROWS, max_boxes);
+        dim3 grid2((S / 2 + 127) / 128, (S + CROP2_ROWS - 1) / CROP2_ROWS, (max_boxes + 7) / 8 * 8);
         if (mode == 2)
             hipLaunchKernelGGL(crop_resize2_kernel<2>, grid2, dim3(128, CROP2_ROWS), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
-                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2], ext);
+                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2], ext, max_boxes);
         else
             hipLaunchKernelGGL(crop_resize2_kernel<1>, grid2, dim3(128, CROP2_ROWS), 0, (hipStream_t)stream, img, boxes, count_dev, (bf16_t*)out,
-                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2], ext);
+                               H0, W0, S, m[0], m[1], m[2], s[0], s[1], s[2], ext, max_boxes);
         return cvpce_check_launch();
     }
     hipLaunchKernelGGL(crop_resize_kernel, grid, dim3(128), 0, (hipStream_t)stream, img, boxes, count_dev, out, H0, W0,

@@ -752,7 +752,7 @@ def gln_transform_batch(images, batch, sizes, mean, std):
         prof.layer('gln_transform_batch', 0.0, _nbytes(batch, *images), e0, e1)
 
 
-MAX_CROPS_PER_LAUNCH = 65535
+MAX_CROPS_PER_LAUNCH = 65528   # (the grid z limit, a multiple of 8: the crop kernel deals crops to XCDs in groups of 8)
 
 
 def crop_resize(img, boxes, size=256, mode=0, mean=None, std=None, count=None, out=None, content_ext=None):
