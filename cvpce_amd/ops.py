@@ -307,8 +307,8 @@ CONV_SPLITK = _os.environ.get('CVPCE_CONV_SPLITK', '1') != '0'   # A/B switch: s
 
 def splitk_factor(pc, ho, wo):
     """Workgroups per output tile for a conv that the 128-cout register-staged kernel would run: a function of the LAYER shape only
-    (K-steps, map size), 0 = unsplit.  36+ K-steps on an output map of at most 32 x 32: 4 (tools/dev/bench_splitk.py: 62 -> 41 us for layer4's 3x3 on
-    4 images, 34 -> 24 us for P6 / P7; a 50 x 50 output map has workgroups enough and loses 2-10 us to the partial tiles' round trip)."""
+    (K-steps, map size), 0 = unsplit.  36+ K-steps on an output map of at most 32 x 32: 4 (tools/dev/prof_splitk.sh, kernel durations on 4 images:
+    layer4's 3x3 62.6 -> 28.8 + 6.4 us, P6 / P7 34 -> 11 + 4 us; a 50 x 50 output map has workgroups enough: 37.8 -> 29.0 + 7-10 us, not split)."""
     if not CONV_SPLITK or pc.cin_pad % 64 != 0 or pc.cout <= 64 or pc.k_pad // 64 < 32:
         return 0
     return 4 if ho * wo <= 1024 else 0
