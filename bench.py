@@ -66,6 +66,9 @@ def parse():
     ap.add_argument('--no-h2d', action='store_true', help='skip the H2D-inclusive leg')
     ap.add_argument('--no-precision-leg', action='store_true', help='skip the extra timed window in the other detector precision')
     ap.add_argument('--no-coheadlines', action='store_true', help='skip the lists-off / planted-box whole-pipeline windows (value_lists_off, value_planted_boxes)')
+    ap.add_argument('--allow-stub', action='store_true', help='tests only: honour CVPCE_BENCH_STUB (a CPU stand-in for the HIP pipeline; the line is stamped "stub")')
+    ap.add_argument('--details', default=None, help='where rank 0 writes the FULL result object (per-layer tables, stages, every co-headline object); '
+                                                    'default bench_details.json beside bench.py.  The printed line is the compact form (< 4 KB) and names this file')
     return ap.parse_args()
 
 
@@ -119,6 +122,7 @@ def cpu_baseline(det_sd, enc_sd, dpi, gallery_emb, image_size):
     t_match = time.perf_counter() - t
     per_image = t_det + t_embed * dpi + t_match
     return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample_short': f'oracle fp32 torch CPU: {n_img} img detect {t_det:.2f} s/img + {n_crop} crops {t_embed * 1e3:.0f} ms/crop + literal match; per image P={dpi}',
             'sample': f'oracle (fp32 torch CPU restatement): detector {n_img} images {image_size}x{image_size} at {t_det:.2f} s/image + '
                       f'crop+embed {n_crop} crops at {t_embed * 1e3:.0f} ms/crop + literal matcher {n_batches} x 32 queries x '
                       f'{len(gallery_emb)} gallery {t_match:.2f} s; extrapolated to P={dpi} proposals/image'}
@@ -243,6 +247,15 @@ def conv_roofline(summ, stages=None):
            # the layers' ALGORITHMIC FLOPs over the same time: a throughput in units of whole crops, NOT a hardware rate (it can exceed
            # the MFMA peak where padding tiles are skipped) -- never compare it with `peak`
            'images_equivalent_tflops': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
+    st = summ.get(name + '[strips]')
+    if st and st['ms'] > 0:
+        # the same kernel's STRIP template instance (tiles with 4 useful rows, three per pass): its own launches, duration and executed
+        # FLOPs -- never averaged with the LIST launches above (round 5 published a 970 us mean of the two populations)
+        out['strip_launches'] = {'launches': st['launches'], 'avg_launch_us': round(st['ms'] * 1e3 / st['launches'], 2), 'total_ms': round(st['ms'], 3),
+                                 'executed_tflop': round(st['flops_executed'] / 1e12, 3), 'achieved': round(st['flops_executed'] / (st['ms'] * 1e-3) / 1e12, 2),
+                                 'frac': round(st['flops_executed'] / (st['ms'] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+    out['total_ms'] = round(dom['ms'], 3)
+    out['executed_tflop'] = round(dom.get('flops_executed', dom['flops']) / 1e12, 3)
     if traffic_note:
         out['traffic_note'] = traffic_note
     if stages is not None:
@@ -497,6 +510,9 @@ def build_pipeline(args, rank, world, dev, ipg, dpi):
             't_gallery': t_gallery, 'det_sd': det_sd, 'enc_sd': enc_sd}
 
 
+ALLOW_STUB = False      # main(): --allow-stub (tests only)
+
+
 def stub_factory():
     """CVPCE_BENCH_STUB='module:function' (tests only): a CPU stand-in for `build_pipeline` with the same signature and keys, so that
     main() -- argument parsing, sharding, the gallery all_gather, the timed windows' barriers and MAX reduction, the --verify gather,
@@ -505,6 +521,8 @@ def stub_factory():
     spec = os.environ.get('CVPCE_BENCH_STUB')
     if not spec:
         return None
+    if not ALLOW_STUB:
+        sys.exit('bench.py: CVPCE_BENCH_STUB is set but --allow-stub was not passed: refusing to replace the HIP pipeline with a stand-in')
     import importlib
     mod, fn = spec.split(':')
     return getattr(importlib.import_module(mod), fn)
@@ -515,6 +533,18 @@ def run_pipeline(args, rank, local_rank, world, dev):
     ipg = args.images_per_gpu or 8
     dpi = args.detections_per_img or 200
     stub = stub_factory()
+    leg_errors = {}
+
+    def leg(name, fn, *a, **kw):
+        """A rank-0 side leg: its failure is recorded on the line (`leg_errors`), it never takes the measurement down with it."""
+        try:
+            return fn(*a, **kw)
+        except Exception as e:                               # noqa: BLE001
+            import traceback
+            leg_errors[name] = f'{type(e).__name__}: {e}'
+            print(f'[bench] leg {name} failed:\n{traceback.format_exc()}', file=sys.stderr, flush=True)
+            return None
+
     if stub is not None:
         args.no_h2d = args.no_roofline = args.no_workloads = args.no_peaks = args.no_parity = args.no_cpu_baseline = True
         args.no_precision_leg = args.no_coheadlines = True
@@ -559,41 +589,47 @@ def run_pipeline(args, rank, local_rank, world, dev):
         # what the timed windows themselves issued: per window two barriers + one MAX reduction of the window's seconds, at the window
         # boundaries -- nothing between the steps (no steady-state collectives)
         collectives['in_timed_windows'] = {k: coll_after[k] - coll_before[k] for k in ('all_gather', 'all_reduce', 'barrier')}
-        collectives['data_path_collectives_per_step'] = 0
+        # derived, not asserted: what the windows issued beyond their own boundary operations, per timed step
+        nw = max(1, args.windows)
+        itw = collectives['in_timed_windows']
+        extra = itw['all_gather'] + max(0, itw['all_reduce'] - nw) + max(0, itw['barrier'] - 2 * nw)
+        collectives['data_path_collectives_per_step'] = extra / (nw * args.steps) if extra else 0
         collectives['gallery_all_gather_mb'] = round(collectives['all_gather_bytes_received'] / 1e6, 2)
 
     # ---- rank-0-only side legs (no collectives below this line: the other ranks are on their way out) -----------------------------
     # the same step with the detector in its OTHER storage mode (fp16 = the product default, the mode that meets the parity tolerance,
     # DESIGN.md 2a; bf16 = the opt-in): one more timed window
-    by_precision = None
-    if rank == 0 and not args.no_precision_leg:
+    def precision_leg():
         other = 'fp16' if args.detector_precision == 'bf16' else 'bf16'
         det2 = synthetic.synthetic_gln(seed=0, detections_per_img=dpi, precision=other).to(dev)
         pipe2 = production.BatchedPipeline(det2, clf, 0.5)
         for _ in range(max(2, args.warmup)):
             pipe2.run(images)
         t2, _ = timed_windows(lambda: pipe2.run(images), args.steps, 1, dev, collective=False)
-        by_precision = {args.detector_precision: round(ipg * args.steps / elapsed, 3), other: round(ipg * args.steps / t2, 3),
-                        'note': 'images/s per GPU with the detector storing fp16 (default) / bf16; the second figure is one extra timed window of '
-                                '--steps steps on rank 0 right after the headline windows, same box, same images'}
-        del pipe2, det2
+        return {args.detector_precision: round(ipg * args.steps / elapsed, 3), other: round(ipg * args.steps / t2, 3),
+                'note': 'images/s per GPU with the detector storing fp16 (default) / bf16; the second figure is one extra timed window of '
+                        '--steps steps on rank 0 right after the headline windows, same box, same images'}
+
+    by_precision = leg('precision', precision_leg) if (rank == 0 and not args.no_precision_leg) else None
 
     if rank == 0 and built.get('rank0_leg') is not None:
         built['rank0_leg']()
     cohead = None
     if rank == 0 and not args.no_coheadlines:
-        cohead = coheadline_legs(pipe, images, ipg, dpi, args.image_size, args.steps, dev)
+        cohead = leg('coheadlines', coheadline_legs, pipe, images, ipg, dpi, args.image_size, args.steps, dev)
+    if cohead is not None:
         cohead['headline'] = dict({'images_per_s': round(ipg * args.steps / elapsed, 3), 'proposals_per_image': proposals}, **crop_shape_stats(
             torch.cat([out['boxes'][i, :c] for i, c in enumerate(out['counts_host'])])))
 
-    roofline = None
-    if not args.no_roofline and rank == 0:
+    def roofline_leg():
         ops.PROFILE = ops.ConvProfile()
-        for _ in range(args.steps):
-            pipe.run(images)
-        summ = ops.PROFILE.summary()
-        summ_bytes = ops.PROFILE.summary_bytes()
-        ops.PROFILE = None
+        try:
+            for _ in range(args.steps):
+                pipe.run(images)
+            summ = ops.PROFILE.summary()
+            summ_bytes = ops.PROFILE.summary_bytes()
+        finally:
+            ops.PROFILE = None
         alg_conv = sum(v['flops'] for v in summ.values()) / args.steps / 1e9
         exe_conv = sum(v.get('flops_executed', v['flops']) for v in summ.values()) / args.steps / 1e9
         stage_events = []                 # a separate pass: the per-launch events above slow the small detector launches
@@ -623,10 +659,7 @@ def run_pipeline(args, rank, local_rank, world, dev):
                                   'images_equivalent_tflops': round(alg_step / (elapsed / args.steps * 1e3), 1)}
         # shape of the crops of this step (the padding a crop carries is 1 - short / long side of its box)
         c0 = out['counts_host']
-        bx = torch.cat([out['boxes'][i, :c0[i]] for i in range(len(images))]).to(torch.long).float()
-        bw, bh = (bx[:, 2] - bx[:, 0]).clamp(min=1), (bx[:, 3] - bx[:, 1]).clamp(min=1)
-        roofline['crop_shapes'] = {'short_over_long_mean': round(float((torch.minimum(bw, bh) / torch.maximum(bw, bh)).mean()), 4),
-                                   'wide_fraction': round(float((bw > bh).float().mean()), 4)}
+        roofline['crop_shapes'] = crop_shape_stats(torch.cat([out['boxes'][i, :c0[i]] for i in range(len(images))]))
         if not args.no_clocks:
             # the clock and the power the card delivers while it runs this step (and, for comparison, its bare MFMA loop)
             with ClockSampler(dev) as cs:
@@ -644,25 +677,30 @@ def run_pipeline(args, rank, local_rank, world, dev):
                                       'frac_at_step_clock': round(roofline['achieved'] / at_clock, 4),
                                       'note': 'amdgpu hwmon freq1_input / power1 sampled every 20 ms over 1.5 s of steps; `frac` above stays '
                                               'against the nominal 2.4 GHz peak'}
+        return roofline
 
-    workloads = None
-    if not args.no_workloads and rank == 0:
+    roofline = leg('roofline', roofline_leg) if (not args.no_roofline and rank == 0) else None
+
+    def workloads_leg():
         # BASELINE configs[1] and configs[3] on this same box (a few hundred ms of GPU time): the driver only runs the default line
         # (taken BEFORE the CPU-heavy legs: the oracle's OpenMP threads keep spinning for a while and slow the launch path)
         w = detector_workload(dev, 4, 1000, args.image_size, max(10, args.steps), max(3, args.warmup), args.detector_precision, collective=False, want_layers=True)
-        workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')},
-                     'match_stress_configs3': match_stress_cases(dev, 200, 3),
-                     'embed_planted_boxes': embed_planted_boxes(dev, enc, images[0], ipg * dpi)}
-        fs = fitted_scenes_pipeline(dev, clf, ipg, dpi, args.image_size, max(5, args.steps // 2), args.detector_precision)
+        workloads = {'detector_configs1': {k: v for k, v in w.items() if not k.startswith('_')}}
+        workloads['match_stress_configs3'] = leg('match_stress', match_stress_cases, dev, 200, 3)
+        workloads['embed_planted_boxes'] = leg('embed_planted_boxes', embed_planted_boxes, dev, enc, images[0], ipg * dpi)
+        fs = leg('fitted_scenes', fitted_scenes_pipeline, dev, clf, ipg, dpi, args.image_size, max(5, args.steps // 2), args.detector_precision)
         if fs is not None:
             workloads['pipeline_fitted_scenes'] = fs
+        return {k: v for k, v in workloads.items() if v is not None}
 
-    peaks = measured_peaks(dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
+    workloads = leg('workloads', workloads_leg) if (not args.no_workloads and rank == 0) else None
+
+    peaks = leg('peaks', measured_peaks, dev) if (rank == 0 and not args.no_peaks and not args.no_roofline) else None
     if roofline is not None and peaks is not None:
         bare = peaks['bare_mfma_loop_tflops']
         roofline['frac_of_bare_mfma_loop'] = round(roofline['achieved'] / max(bare['32x32x16'], bare['16x16x32']), 4)
-    parity = None
-    if not args.no_parity and rank == 0 and world == 1:
+
+    def parity_leg():
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         import accuracy                                           # tests/accuracy.py: the oracle as CHECKER (never timed, never shipped)
         torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -687,9 +725,12 @@ def run_pipeline(args, rank, local_rank, world, dev):
                             f'precision of this run ({args.detector_precision}: fp16 is the product default), by_precision = both detector modes (fp16 default, bf16 opt-in); '
                             '64 paired detections + 64 ground-truth crops vs a 256-product gallery; full-size figures (32 images, '
                             'G = 1000 / 3200): profiles/r05_accuracy.json')
+        return parity
+
+    parity = leg('parity', parity_leg) if (not args.no_parity and rank == 0 and world == 1) else None
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
+        cpu = leg('cpu_baseline', cpu_baseline, det_sd, enc_sd, dpi, gallery.float().cpu(), args.image_size)
     if rank != 0:
         return None
     total_images = world * ipg * args.steps
@@ -727,6 +768,14 @@ def run_pipeline(args, rank, local_rank, world, dev):
                      ('cpu_baseline', cpu), ('workloads', workloads), ('verify', verify)):
         if val is not None:
             line[key] = val
+    if leg_errors:
+        line['leg_errors'] = leg_errors
+    if stub is not None:
+        # a rehearsal with a CPU stand-in for the HIP pipeline (tests only): never a measurement, and the line says so
+        line['stub'] = os.environ.get('CVPCE_BENCH_STUB')
+        line['metric'] = 'STUB (CPU stand-in, not a measurement): ' + line['metric']
+        line['data'] = 'stub'
+        line['config']['weights'] = line['config']['detector_precision'] = None
     return line
 
 
@@ -980,6 +1029,114 @@ def run_match_stress(args, rank, local_rank, world, dev):
                          'avg_launch_us': head['us_per_launch'], 'cases': cases}}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the printed line: compact (< 4 KB); everything else goes to the details file
+# ---------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+BASE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
+ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launches', 'avg_launch_us')
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full, details_name):
+    """The ONE line rank 0 prints: the contract's base keys, `config` (workload string + scalars), the co-headline values, `roofline`
+    (the dominant kernel: scalars only), `cpu_baseline`, `parity` (scalars), `verify` (image count + digest) -- nothing nested deeper,
+    no tables.  `full` (written to `details_name`) keeps every object."""
+    line = _pick(full, BASE_KEYS)
+    cfg = full.get('config', {})
+    c = {'workload': str(cfg.get('workload', ''))[:400]}
+    c.update(_pick(cfg, ('images_per_gpu', 'global_images', 'proposals_per_image', 'gallery', 'match_dtype', 'detector_precision', 'kept_per_image',
+                         'parallelism', 'gallery_build_s')))
+    if isinstance(c.get('parallelism'), str):
+        c['parallelism'] = c['parallelism'].split(' ')[0]
+    coll = cfg.get('collectives')
+    c['collectives'] = None if coll is None else _pick(coll, ('backend', 'world_size', 'all_gather', 'data_path_collectives_per_step'))
+    line['config'] = c
+    for k in ('value_lists_off', 'value_planted_boxes', 'value_fitted_scenes_p200', 'value_with_h2d', 'stub'):
+        if k in full:
+            line[k] = full[k]
+    if isinstance(full.get('windows'), dict):
+        line['windows_ms_per_step'] = full['windows'].get('ms_per_step')
+    r = full.get('roofline')
+    if isinstance(r, dict):
+        cr = _pick(r, ROOFLINE_KEYS)
+        if isinstance(r.get('lists_off'), dict):
+            cr['lists_off_frac'] = r['lists_off'].get('frac')
+            cr['lists_off_avg_launch_us'] = r['lists_off'].get('avg_launch_us')
+        if isinstance(r.get('end_to_end'), dict):
+            cr['end_to_end_frac'] = r['end_to_end'].get('frac_of_mfma_peak')
+        if isinstance(r.get('strip_launches'), dict):
+            cr['strip_launches'] = _pick(r['strip_launches'], ('launches', 'avg_launch_us', 'frac'))
+        if isinstance(r.get('stages'), dict):
+            cr['stage_ms'] = {k: v.get('ms_per_step') for k, v in r['stages'].items() if isinstance(v, dict)}
+        if isinstance(r.get('clocks'), dict):
+            cr['sclk_mhz'] = r['clocks'].get('step', {}).get('sclk_mhz_median')
+            cr['power_w'] = r['clocks'].get('step', {}).get('power_w_median')
+        if 'frac_of_bare_mfma_loop' in r:
+            cr['frac_of_bare_mfma_loop'] = r['frac_of_bare_mfma_loop']
+        line['roofline'] = cr
+    cb = full.get('cpu_baseline')
+    if isinstance(cb, dict):
+        line['cpu_baseline'] = dict(_pick(cb, ('value', 'unit', 'cores', 'kind')), sample=str(cb.get('sample_short') or cb.get('sample', ''))[:120])
+    p = full.get('parity')
+    if isinstance(p, dict):
+        # random-weight detector vs the fp32 oracle: how many oracle boxes are found at IoU > 0.9, the mean corner difference of paired
+        # boxes, top-1 agreement of the matcher; fitted detector (finds the pasted products): mAP / AR300 / top-1 deltas against the TRUE boxes
+        cp = _pick(p, ('images', 'frac_oracle_boxes_iou90', 'paired_box_diff_px_mean', 'ap50_area_vs_oracle', 'ar300_vs_oracle'))
+        g = next((v for k, v in p.items() if k.startswith('G') and isinstance(v, dict)), {})
+        cp.update({'top1_agree': g.get('top1_agree'), 'top1_acc_delta_pt': g.get('top1_acc_delta_pt')})
+        f = p.get('fitted_detector', {}).get('by_precision', {}).get(cfg.get('detector_precision'), {}) if isinstance(p.get('fitted_detector'), dict) else {}
+        for k in ('map_delta_pt_true_gt', 'ar300_delta_pt_true_gt'):
+            if k in f:
+                cp['fitted_' + k] = f[k]
+        t1 = [v for k, v in f.items() if k.startswith('pipeline_top1_delta_pt')]
+        if t1:
+            cp['fitted_top1_delta_pt'] = t1[0]
+        line['parity'] = cp
+    w = full.get('workloads')
+    if isinstance(w, dict):
+        cw = {}
+        if isinstance(w.get('detector_configs1'), dict):
+            cw['detector_configs1'] = _pick(w['detector_configs1'], ('images', 'ms_per_step', 'images_per_s', 'frac_of_mfma_peak'))
+        if isinstance(w.get('match_stress_configs3'), list):
+            cw['match_stress_configs3_us'] = {f"{e['P']}x{e['G']}x{e['D']}": e['us_per_launch'] for e in w['match_stress_configs3']}
+        line['workloads'] = cw
+    v = full.get('verify')
+    if isinstance(v, dict):
+        line['verify'] = _pick(v, ('images', 'digest'))
+    if full.get('leg_errors'):
+        line['leg_errors'] = {k: str(e)[:80] for k, e in full['leg_errors'].items()}
+    line['details'] = details_name
+    return line
+
+
+def emit(full, details_path):
+    """Write the full object to `details_path` (a failure to write is reported on the line, never fatal) and return the compact
+    line as a JSON string of < LINE_LIMIT bytes: optional objects are dropped, largest first, if it would ever be longer."""
+    name = os.path.basename(details_path)
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(details_path)), exist_ok=True)
+        with open(details_path, 'w') as f:
+            json.dump(full, f, indent=1, default=str)
+    except OSError as e:
+        name = f'not written ({type(e).__name__})'
+    line = compact_line(full, name)
+    s = json.dumps(line, separators=(',', ':'), default=str)
+    for k in ('workloads', 'parity', 'windows_ms_per_step', 'leg_errors', 'verify', 'cpu_baseline', 'roofline'):
+        if len(s) < LINE_LIMIT:
+            break
+        if k in ('cpu_baseline', 'roofline'):                # (never dropped whole: cut to the contract's own keys)
+            line[k] = _pick(line[k], ROOFLINE_KEYS if k == 'roofline' else ('value', 'unit', 'cores', 'kind'))
+        else:
+            line.pop(k, None)
+        s = json.dumps(line, separators=(',', ':'), default=str)
+    assert len(s) < LINE_LIMIT, len(s)
+    return s
+
+
 def host_threads_for(world, cores):
     """Host threads one rank may use: its share of the node's cores (image synthesis, pinned staging and the oracle legs use torch's
     intra-op pool; N ranks on one node must not each claim every core)."""
@@ -987,7 +1144,9 @@ def host_threads_for(world, cores):
 
 
 def main():
+    global ALLOW_STUB
     args = parse()
+    ALLOW_STUB = args.allow_stub
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_launcher(args))
     from cvpce_amd import dist as cdist
@@ -1001,9 +1160,9 @@ def main():
     else:
         dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))   # (a 1-GPU rehearsal may stack ranks on cuda:0)
         torch.cuda.set_device(dev)
-    line = {'pipeline': run_pipeline, 'detector': run_detector, 'match-stress': run_match_stress}[args.workload](args, rank, local_rank, world, dev)
+    full = {'pipeline': run_pipeline, 'detector': run_detector, 'match-stress': run_match_stress}[args.workload](args, rank, local_rank, world, dev)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(emit(full, args.details or os.path.join(ROOT, 'bench_details.json')), flush=True)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         # Rank 0 runs its side legs (roofline, parity, CPU baseline: ~2 min) after the last collective; the other ranks have nothing left to

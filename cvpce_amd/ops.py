@@ -652,16 +652,18 @@ def conv2d_list(x, pc, work, count, act=1, pool=False, mac=None, mac_off=0, stor
         e1.record()
         wide = pc.cout <= 128
         tile_flops = 2.0 * 16 * (32 if wide else 16) * pc.cout * 9 * pc.cin
-        # (`units` counts the layer's whole MFMA work, its strip launch included: the strip record below carries none)
+        # (`units` counts the layer's whole MFMA work in sixteenths of a tile, its strip launch included: a strip-list entry is 4 of
+        # them (csrc/skiplist.hip) and is filed with the STRIP launch below, a different template instance with its own duration)
+        lunits = (units - 4 * strips[1]) if (units is not None and strips is not None) else units
         prof.records.append(('conv3x3_halo3_kernel' if wide else 'conv3x3_halo2_kernel', 2.0 * (n - 1) * h * w * pc.cout * 9 * pc.cin, e0, e1)
-                            + ((units, tile_flops / 16) if units is not None else (count, tile_flops)) + (f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else ''),))
+                            + ((lunits, tile_flops / 16) if units is not None else (count, tile_flops)) + (f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else ''),))
     if strips is not None:
         assert pc.cout > 128
         T.conv3x3_halo_strips(x, pc.weight_halo, pc.bias, out, mac, int(mac_off), pc.cout, pc.k_pad, pc.cout_pad, int(act), int(pool and store), strips[0], strips[1])
         if prof is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
-            prof.records.append(('conv3x3_halo2_kernel', 0.0, e1, e2, None, 0.0, f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else '')))
+            prof.records.append(('conv3x3_halo2_kernel[strips]', 0.0, e1, e2, strips[1], tile_flops / 4, f'{pc.cin}->{pc.cout}@{h}' + ('mac' if mac is not None else '')))
     return out
 
 

@@ -109,12 +109,23 @@ def _bench_stub(gpus, extra=()):
                PYTHONPATH=os.pathsep.join([os.path.join(root, 'tests'), root, os.environ.get('PYTHONPATH', '')]))
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '3', '--warmup', '1', '--gallery', '203',
-                        '--images-per-gpu', '8', '--verify', *extra], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line, the other ranks nothing
-    return json.loads(lines[0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        det = os.path.join(tmp, 'details.json')
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '3', '--warmup', '1', '--gallery', '203',
+                            '--images-per-gpu', '8', '--verify', '--allow-stub', '--details', det, *extra], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line, the other ranks nothing
+        assert len(lines[0]) < 4096                                   # ... that the driver can parse (round 5's 23 KB line could not be)
+        line, full = json.loads(lines[0]), json.load(open(det))
+    # a stand-in run is stamped: it can never be mistaken for a measurement
+    assert line['stub'] == 'bench_stub:build' and line['metric'].startswith('STUB') and line['data'] == 'stub'
+    # the compact line carries what a scaling run is checked by (world size the process group saw, the job digest) without the details file
+    assert line['config']['collectives']['world_size'] == full['config']['collectives']['world_size'] == gpus
+    assert line['verify'] == {'images': full['verify']['images'], 'digest': full['verify']['digest']}
+    assert all(line[k] == full[k] for k in ('value', 'n_gpus', 'steps', 'ms_per_step', 'scaling'))
+    return full
 
 
 def test_bench_main_under_8_gloo_ranks():

@@ -1,5 +1,6 @@
-"""bench.py's JSON contract on small inputs: every workload prints ONE line with the fields the driver reads, the roofline
-object, and (pipeline) the H2D-inclusive value, the parity object and the CPU baseline."""
+"""bench.py's JSON contract on small inputs: every workload prints ONE COMPACT line (< 4 KB: round 5's 23 KB line could not be parsed by the
+driver) with the fields the driver reads, the roofline and cpu_baseline objects, and writes the full result object (tables, stages,
+co-headline objects) to the details file the line names."""
 import json
 import os
 import subprocess
@@ -12,16 +13,48 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'}
 
 
-def _run(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+def _run(tmp_path, *args):
+    """-> (the printed line, the details object)."""
+    det = os.path.join(str(tmp_path), 'details.json')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args, '--details', det], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
-    return json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])                      # the driver must be able to parse it
+    line = json.loads(lines[0])
+    assert line['details'] == 'details.json' and 'leg_errors' not in line, line.get('leg_errors')
+    return line, json.load(open(det))
 
 
-def test_pipeline_line_small(cuda):
-    d = _run('--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--gallery', '128', '--no-peaks')
+def _check_compact(c, d):
+    """the compact line `c` carries the details object `d`'s headline figures unchanged, and nothing nested deeper than one level below
+    its top-level objects."""
+    for k in BASE - {'config'}:
+        assert c[k] == d[k], k
+    assert c['config']['workload'] == d['config']['workload'][:400]
+    r, rd = c['roofline'], d['roofline']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(r)
+    assert all(r[k] == rd[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'))
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    for v in c.values():
+        if isinstance(v, dict):
+            assert all(not isinstance(x, list) or len(x) <= 8 for x in v.values())
+            assert all(not isinstance(y, (dict, list)) for x in v.values() if isinstance(x, dict) for y in x.values())
+
+
+def test_pipeline_line_small(cuda, tmp_path):
+    c, d = _run(tmp_path, '--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--gallery', '128', '--no-peaks')
+    _check_compact(c, d)
+    assert BASE <= set(c) and c['config']['detector_precision'] == 'fp16' and c['config']['collectives'] is None
+    assert c['value_lists_off'] == d['value_lists_off'] and c['value_planted_boxes'] == d['value_planted_boxes'] and c['value_with_h2d'] == d['value_with_h2d']
+    assert c['value_fitted_scenes_p200'] == d['value_fitted_scenes_p200']
+    assert c['roofline']['kernel'] == 'conv3x3_halo2_kernel' and c['roofline']['lists_off_frac'] == d['roofline']['lists_off']['frac']
+    assert c['roofline']['end_to_end_frac'] == d['roofline']['end_to_end']['frac_of_mfma_peak'] and set(c['roofline']['stage_ms']) == {'detect', 'crop', 'embed', 'match'}
+    cb = c['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] == d['cpu_baseline']['value'] > 0 and 0 < len(cb['sample']) <= 120
+    assert c['parity']['images'] == 4 and 0.9 < c['parity']['frac_oracle_boxes_iou90'] <= 1.0 and abs(c['parity']['fitted_map_delta_pt_true_gt']) <= 1.0
+    assert c['workloads']['detector_configs1']['ms_per_step'] == d['workloads']['detector_configs1']['ms_per_step']
+    assert len(c['workloads']['match_stress_configs3_us']) == 4
     assert BASE <= set(d) and d['unit'] == 'images/s' and d['n_gpus'] == 1 and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['dtype'] == 'bf16' and 'workload' in d['config'] and d['value'] > 0
     r = d['roofline']
@@ -77,9 +110,11 @@ def test_pipeline_line_small(cuda):
     assert {e['bound'] for e in ly['classes']} >= {'mfma', 'hbm', 'latency'}
     assert all(0 < e['frac_of_roof'] <= 1.0 for e in ly['classes'] if e['bound'] != 'latency'), ly['classes']
 
-def test_detector_and_match_stress_lines(cuda):
-    d = _run('--workload', 'detector', '--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--no-cpu-baseline')
+def test_detector_and_match_stress_lines(cuda, tmp_path):
+    c, d = _run(tmp_path, '--workload', 'detector', '--steps', '2', '--warmup', '1', '--images-per-gpu', '2', '--image-size', '1024', '--no-cpu-baseline')
+    _check_compact(c, d)
     assert BASE <= set(d) and 'detector' in d['metric'] and d['roofline']['stages']['detect']['ms_per_step'] > 0
-    m = _run('--workload', 'match-stress', '--steps', '2')
+    cm, m = _run(tmp_path, '--workload', 'match-stress', '--steps', '2')
+    _check_compact(cm, m)
     assert BASE <= set(m) and m['unit'] == 'queries/s' and m['roofline']['bound'] == 'hbm' and len(m['roofline']['cases']) == 4
     assert {(c['P'], c['D']) for c in m['roofline']['cases']} == {(200, 512), (200, 1024), (1600, 512), (1600, 1024)}

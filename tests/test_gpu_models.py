@@ -106,8 +106,19 @@ def test_config1_plumbing_and_parity(cuda, gln_model):
     # oracle
     ref = og.gln_forward([img], sd, detections_per_img=200)[0]
     g = r['gaussians'].cpu()
-    assert l2rel(g, ref['gaussians']) < 0.25
-    _compare_detections(r, ref)
+    # the product default (fp16 storage) measures l2rel 0.013 and 99 % of the oracle's boxes at IoU > 0.9 here: the gates sit just
+    # above that, so a regression to bf16-level agreement (0.11, 93 %) fails
+    assert model.precision == 'fp16'
+    assert l2rel(g, ref['gaussians']) < 0.05, l2rel(g, ref['gaussians'])
+    _compare_detections(r, ref, min_frac=0.95)
+    # the opt-in bf16 storage keeps the loose bounds (7 mantissa bits through 50+ random-weight layers)
+    model.set_precision('bf16')
+    try:
+        rb = model([img.to(cuda)])[0]
+    finally:
+        model.set_precision('fp16')
+    assert l2rel(rb['gaussians'].cpu(), ref['gaussians']) < 0.25
+    _compare_detections(rb, ref, min_frac=0.8)
 
 
 def _compare_detections(r, ref, min_frac=0.8):
@@ -156,7 +167,8 @@ def _gln_intermediates_and_stage_exact(cuda, model, sd, og):
         assert (got.view(2, -1).cpu() - want.view(2, -1)).abs().max() < 0.15 * want.std() + 0.05
     for got, want in zip(inter['reg'], rint['reg']):
         assert (got.view(2, -1).cpu() - want.view(2, -1)).abs().max() < 0.15 * want.std() + 0.02
-    assert l2rel(gauss.cpu(), rint['gaussians']) < 0.25     # ill-conditioned with random weights (sparse ReLU output)
+    # ill-conditioned with random weights (sparse ReLU output): fp16 storage (the default) measures 0.011, bf16 0.118
+    assert l2rel(gauss.cpu(), rint['gaussians']) < (0.05 if model.precision == 'fp16' else 0.25), l2rel(gauss.cpu(), rint['gaussians'])
     # (2) every stage against the CPU model of the SAME numerics, fed the GPU's own stage inputs: tight
     from oracle import bf16_model as bm
     nm = bm.FP16 if model.precision == 'fp16' else bm.BF16
@@ -187,7 +199,8 @@ def _gln_intermediates_and_stage_exact(cuda, model, sd, og):
         assert int(conf[i]) == int((s > 0.5).sum())
     for i in range(n):
         c = int(count[i])
-        _compare_detections({'boxes': boxes[i, :c], 'scores': scores[i, :c]}, ref[i], min_frac=0.7)
+        # (fp16 measures 97.5 / 98.5 % of the oracle's boxes at IoU > 0.9 on these two images, bf16 90 %)
+        _compare_detections({'boxes': boxes[i, :c], 'scores': scores[i, :c]}, ref[i], min_frac=0.95 if model.precision == 'fp16' else 0.7)
 
 
 def test_pipeline_matches_per_image_api(cuda, gln_model, vgg_model):
