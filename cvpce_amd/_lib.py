@@ -46,6 +46,7 @@ SIGNATURES = {
     'cvpce_pack_halo_weights': (c_int, [_vp, _vp, c_int, c_int]),
     'cvpce_conv3x3_thin_bf16': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_gauss_tail_bf16': (c_int, [_vp, _vp, _fp, _vp, _fp, _fp, c_longlong, c_int, c_int, _vp]),
+    'cvpce_gauss_subnet_bf16': (c_int, [_vp, _vp, _fp, _vp, _fp, _vp, _fp, _vp, _fp, c_int, _vp, _fp, c_int, _fp, c_int, c_int, c_int, c_int, _vp]),
     'cvpce_global_max_nhwc_bf16': (c_int, [_vp, _fp, c_int, c_int, c_int, c_int, c_int, _vp]),
     'cvpce_l2_normalize_f32': (c_int, [_fp, _fp, _vp, c_int, c_int, c_float, _vp]),
     'cvpce_gln_transform': (c_int, [_fp, _vp] + [c_int] * 6 + [POINTER(c_float), POINTER(c_float), _vp]),
@@ -85,7 +86,7 @@ for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpc
                      ('cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16'), ('cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16'),
                      ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_thin_out', 'cvpce_conv3x3_halo_thin_out_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
                      ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'), ('cvpce_bottleneck_fused_fm', 'cvpce_bottleneck_fused_fm_f16'),
-                     ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'), ('cvpce_gauss_tail_bf16', 'cvpce_gauss_tail_f16'), ('cvpce_conv3x3_thin_bf16', 'cvpce_conv3x3_thin_f16'),
+                     ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'), ('cvpce_gauss_tail_bf16', 'cvpce_gauss_tail_f16'), ('cvpce_gauss_subnet_bf16', 'cvpce_gauss_subnet_f16'), ('cvpce_conv3x3_thin_bf16', 'cvpce_conv3x3_thin_f16'),
                      ('cvpce_gln_transform', 'cvpce_gln_transform_f16'), ('cvpce_gln_transform_batch', 'cvpce_gln_transform_batch_f16')):
     SIGNATURES[_twin] = SIGNATURES[_base]
 

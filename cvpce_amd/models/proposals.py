@@ -389,6 +389,9 @@ class GLNEngine:
         x = ops.conv2d(c2, self.g_lateral, residual=p3, res_mode=2)       # lateral(C2) + up2(P3)
         x = ops.conv2d(x, self.g_block1, act=1)
         x = ops.conv2d(x, self.g_block2, act=1)
+        if ops.can_fuse_gauss_subnet(x, self.g_subnet):
+            # the whole subnet (proposals.py:81-107) over up2(x) in one launch: no intermediate layer reaches memory (csrc/gauss_subnet.hip)
+            return ops.gauss_subnet(x, self.g_subnet, 2 if self.tanh else 1)
         x = ops.conv2d(x, self.g_subnet[0], act=1, in_up_shift=1)         # conv over up2(x), never materialised
         x = ops.conv2d(x, self.g_subnet[1], act=1)
         x = ops.conv2d(x, self.g_subnet[2], act=1)

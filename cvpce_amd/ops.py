@@ -711,6 +711,43 @@ def gauss_tail(x, c4, c5, act):
     return out
 
 
+USE_GAUSS_SUBNET = _os.environ.get('CVPCE_GAUSS_SUBNET', '1') != '0'   # A/B switch: the whole Gaussian subnet in one launch (csrc/gauss_subnet.hip)
+
+
+def can_fuse_gauss_subnet(x, convs):
+    """cvpce_gauss_subnet covers GaussianSubnet as the reference builds it (proposals.py:81-107): 3x3 64 -> 32 over the 2x-upsampled input,
+    3x3 32 -> 32, 3x3 32 -> 16, 1x1 16 -> 16, 1x1 16 -> 1."""
+    if not (USE_GAUSS_SUBNET and not FORCE_GENERIC_CONV and len(convs) == 5 and x.dim() == 4 and x.shape[-1] == 64):
+        return False
+    c1, c2, c3, c4, c5 = convs
+    shape = lambda c: (c.cin, c.cin_pad, c.cout, c.kh, c.kw, c.stride, c.pad, c.k_pad)
+    return (all(c.dtype == x.dtype for c in convs) and shape(c1) == (64, 64, 32, 3, 3, 1, 1, 576) and shape(c2) == (32, 32, 32, 3, 3, 1, 1, 288)
+            and shape(c3) == (32, 32, 16, 3, 3, 1, 1, 288) and shape(c4)[:7] == (16, 16, 16, 1, 1, 1, 0) and shape(c5)[:7] == (16, 16, 1, 1, 1, 1, 0)
+            and c4.k_pad % 4 == 0 and x.numel() * 2 < 2 ** 32 - 65536)
+
+
+def gauss_subnet(x, convs, act):
+    """GaussianSubnet.forward on x (N,H/2,W/2,64) bf16 | fp16, GaussianLayer's output BEFORE its 2x upsample -> (N,H,W,1) f32;
+    act 1 = ReLU, 2 = Tanh (proposals.py:85).  One launch; no intermediate layer reaches memory."""
+    _need_cuda(x)
+    assert can_fuse_gauss_subnet(x, convs) and x.is_contiguous() and act in (0, 1, 2)
+    c1, c2, c3, c4, c5 = convs
+    n, hs, ws, _ = x.shape
+    out = torch.empty((n, 2 * hs, 2 * ws, 1), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.gauss_subnet(x, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias, c4.weight, c4.bias, c4.k_pad, c5.weight, c5.bias, c5.k_pad, out, int(act))
+    if prof is not None:
+        e1.record()
+        flops = 2.0 * n * 4 * hs * ws * (9 * 64 * 32 + 9 * 32 * 32 + 9 * 32 * 16 + 16 * 16 + 16)
+        prof.records.append(('gauss_subnet_kernel', flops, e0, e1))
+        prof.byte_records.append(('gauss_subnet_kernel', _nbytes(x, out), e0, e1))
+        prof.layer(f'gauss_subnet {2 * hs}x{2 * ws} 64->32->32->16->16->1 (2x upsampled input)', flops, _nbytes(x, out), e0, e1)
+    return out
+
+
 def global_max_into(x, out, out_off):
     """x NHWC bf16 -> out[:, out_off:out_off+C] (f32) = amax over H,W."""
     _need_cuda(x, out)

@@ -178,6 +178,16 @@ def _gauss_tail(x, w2, b2, w3, b3, out, k2_pad, act):
                                                                                k2_pad, act, _stream()), 'gauss_tail')
 
 
+@_op('gauss_subnet(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, Tensor w3, Tensor? b3, Tensor w4, Tensor? b4, int k4_pad, '
+     'Tensor w5, Tensor? b5, int k5_pad, Tensor(a!) out, int act) -> ()')
+def _gauss_subnet(x, w1, b1, w2, b2, w3, b3, w4, b4, k4_pad, w5, b5, k5_pad, out, act):
+    n, hs, ws, c = x.shape
+    assert c == 64 and out.dtype == torch.float32 and tuple(out.shape[:3]) == (n, 2 * hs, 2 * ws) and out.numel() == n * 4 * hs * ws
+    fn = _by_dtype(x, 'cvpce_gauss_subnet_bf16', 'cvpce_gauss_subnet_f16', w1, w2, w3, w4, w5)
+    check(fn(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(w4), _p(b4), k4_pad, _p(w5), _p(b5), k5_pad, _p(out), n, 2 * hs, 2 * ws, act,
+             _stream()), 'gauss_subnet')
+
+
 @_op('global_max_nhwc(Tensor x, Tensor(a!) out, int out_off) -> ()')
 def _global_max_nhwc(x, out, out_off):
     n, h, w, c = x.shape

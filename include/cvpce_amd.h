@@ -174,6 +174,17 @@ int cvpce_relu_bf16(const void* in, void* out, long long n, void* stream);
  * b2 [16] / b3 [1] f32 or NULL -> out [npix] f32.  The hidden layer is rounded to bf16 as the two-launch form stores it. */
 int cvpce_gauss_tail_bf16(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, float* out, long long npix,
                           int k2_pad, int act, void* stream);
+/* The WHOLE GaussianSubnet in one launch (cvpce/models/proposals.py:81-107, called from GaussianLayerNetwork at :139 on the output of
+ * GaussianLayer.forward, :73-79): up2(x) -> conv3x3 64->32 + ReLU -> conv3x3 32->32 + ReLU -> conv3x3 32->16 + ReLU -> conv1x1 16->16 + ReLU
+ * -> conv1x1 16->1 + ReLU (act 1) | Tanh (act 2) | nothing (act 0).  x: [N][H/2][W/2][64] bf16, read through its nearest-2x upsample
+ * (`self.up`, :79, never materialised); H, W: the OUTPUT size (even).  w1 [>= 32 rows][576], w2 [>= 32][288], w3 [>= 16][288]: row-major
+ * 3x3 weights as for cvpce_conv2d_nhwc_bf16 (k = (kh * 3 + kw) * Cin + ci); w4 [>= 16 rows][k4_pad] (k < 16 used), w5 [>= 1 row][k5_pad]
+ * (k < 16 of row 0); b1 [32] b2 [32] b3 [16] b4 [16] b5 [1] f32 or NULL -> out [N][H][W] f32.  Every intermediate layer is rounded to bf16
+ * exactly where the one-launch-per-layer form stores it; none of them reaches memory.  Replaces three cvpce_conv3x3_thin_bf16 launches and
+ * cvpce_gauss_tail_bf16. */
+int cvpce_gauss_subnet_bf16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
+                            const void* w4, const float* b4, int k4_pad, const void* w5, const float* b5, int k5_pad, float* out, int N, int H,
+                            int W, int act, void* stream);
 /* x.amax(dim=(-2,-1)) -> out[n*out_stride + out_off + c]  (classification.py:46-49) */
 int cvpce_global_max_nhwc_bf16(const void* in, float* out, int N, int HW, int C, int out_stride, int out_off,
                                void* stream);
@@ -377,6 +388,9 @@ int cvpce_maxpool2d_nhwc_f16(const void* in, void* out, int N, int H, int W, int
 int cvpce_relu_f16(const void* in, void* out, long long n, void* stream);
 int cvpce_conv3x3_thin_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin, int Cout,
                            int K_pad, int Cout_pad, int relu, int in_up_shift, void* stream);
+int cvpce_gauss_subnet_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
+                           const void* w4, const float* b4, int k4_pad, const void* w5, const float* b5, int k5_pad, float* out, int N, int H,
+                           int W, int act, void* stream);
 int cvpce_gauss_tail_f16(const void* x, const void* w2, const float* b2, const void* w3, const float* b3, float* out, long long npix,
                          int k2_pad, int act, void* stream);
 int cvpce_gln_transform_f16(const float* img, void* out_nhwc8, int H0, int W0, int h, int w, int Hp, int Wp,

@@ -415,6 +415,77 @@ def test_conv3x3_thin_parity(cuda, dtype, n, h, w, cout, act, up):
     assert (y.float() - y2.float()).abs().max() <= (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) * y2.float().abs().max()
 
 
+def _subnet_layers(g, dtype, cuda):
+    from cvpce_amd import ops
+    shapes = [(32, 64, 3), (32, 32, 3), (16, 32, 3), (16, 16, 1), (1, 16, 1)]
+    ws = [torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (k * k * ci)) for co, ci, k in shapes]
+    bs = [torch.randn(co, generator=g) * 0.1 for co, _, _ in shapes]
+    convs = [ops.PackedConv(w, b, 1, 1 if w.shape[-1] == 3 else 0, device=cuda, dtype=dtype) for w, b in zip(ws, bs)]
+    return ws, bs, convs
+
+
+def _subnet_reference(x, ws, bs, act, rd):
+    """GaussianSubnet (proposals.py:81-107) over up2(x) in fp32 on the 16-bit operands, every layer rounded where the kernels store it."""
+    t = F.interpolate(x, scale_factor=2.0, mode='nearest')
+    for i in range(3):
+        t = rd(F.relu(F.conv2d(t, rd(ws[i]), bs[i], padding=1)))
+    t = rd(F.relu(F.conv2d(t, rd(ws[3]), bs[3])))
+    z = F.conv2d(t, rd(ws[4]), bs[4])
+    return torch.tanh(z) if act == 2 else (F.relu(z) if act == 1 else z)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,hs,ws_,act', [(2, 19, 23, 1), (1, 100, 14, 2), (1, 7, 29, 1), (3, 40, 40, 2), (1, 1, 1, 1), (1, 3, 57, 0), (2, 64, 15, 1)])
+def test_gauss_subnet_parity(cuda, dtype, n, hs, ws_, act):
+    """The whole Gaussian subnet in one launch (csrc/gauss_subnet.hip; proposals.py:81-107) against (a) the five layers in fp32 on the same
+    16-bit operands with every layer rounded where the per-layer kernels store it, (b) the per-layer kernels themselves (three thin 3x3
+    launches + the pointwise tail).  Shapes: one strip exactly (W = 28), ragged last strips, maps narrower than a strip, more / fewer rows
+    than a task, a 2 x 2 output (every tap but the centre is zero padding), the image borders of every layer."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(1000 * hs + ws_ + act)
+    rd = lambda t: t.to(dtype).to(torch.float32)
+    wts, bs, convs = _subnet_layers(g, dtype, cuda)
+    x = rd(torch.randn(n, 64, hs, ws_, generator=g).relu())
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(cuda)
+    assert ops.can_fuse_gauss_subnet(xin, convs)
+    got = ops.gauss_subnet(xin, convs, act).cpu()
+    assert got.shape == (n, 2 * hs, 2 * ws_, 1) and got.dtype == torch.float32
+    ref = _subnet_reference(x, wts, bs, act, rd)[:, 0]
+    # (a value that lands on a rounding boundary of the 16-bit type may round the other way under another summation order, and the flip
+    #  is carried through the layers behind it: max error a few ulps of the storage type, mean error far below one)
+    atol, mtol = (3e-2, 1.5e-3) if dtype == torch.bfloat16 else (4e-3, 2e-4)
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got[..., 0] - ref).abs().max() <= atol * scale, ((got[..., 0] - ref).abs().max(), scale)
+    assert (got[..., 0] - ref).abs().mean() <= mtol * scale, ((got[..., 0] - ref).abs().mean(), scale)
+    # (b) the per-layer launches
+    t = xin
+    t = ops.conv2d(t, convs[0], act=1, in_up_shift=1)
+    t = ops.conv2d(t, convs[1], act=1)
+    t = ops.conv2d(t, convs[2], act=1)
+    per_layer = ops.gauss_tail(t, convs[3], convs[4], act).cpu()
+    assert (got - per_layer).abs().max() <= atol * scale and (got - per_layer).abs().mean() <= mtol * scale
+    assert torch.equal(ops.gauss_subnet(xin, convs, act).cpu(), got)                        # deterministic
+
+
+def test_gauss_subnet_full_size_and_batch_independence(cuda):
+    """At the detector's size (200 x 200 stored -> 400 x 400 output, BASELINE configs[1]): an image's map is bit-identical whatever batch
+    it is computed in (the row split over the wave slots depends on N; the arithmetic of a pixel does not), and agrees with the per-layer
+    kernels; also a portrait map (800 x 1088 input -> 400 x 544)."""
+    from cvpce_amd import ops
+    g = torch.Generator().manual_seed(5)
+    wts, bs, convs = _subnet_layers(g, torch.float16, cuda)
+    for hs, ws_ in ((200, 200), (272, 200)):
+        x = torch.randn(8, hs, ws_, 64, generator=g).relu().to(torch.float16).to(cuda)
+        all8 = ops.gauss_subnet(x, convs, 2)
+        for nb in (1, 3, 4):
+            part = ops.gauss_subnet(x[:nb].contiguous(), convs, 2)
+            assert torch.equal(part, all8[:nb]), nb
+        t = ops.conv2d(x[:2].contiguous(), convs[0], act=1, in_up_shift=1)
+        t = ops.conv2d(ops.conv2d(t, convs[1], act=1), convs[2], act=1)
+        per_layer = ops.gauss_tail(t, convs[3], convs[4], 2)
+        assert (all8[:2] - per_layer).abs().max() < 4e-3 and (all8[:2] - per_layer).abs().mean() < 1e-4
+
+
 def test_detect_postprocess_no_candidates(cuda):
     from cvpce_amd import ops
     from cvpce_amd.models import proposals as P

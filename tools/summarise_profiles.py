@@ -13,7 +13,7 @@ def prof_name(k):    # rocprof kernel name -> the name ops.ConvProfile / bench.p
     for p, n in (('conv3x3_halo2_kernel', 'conv3x3_halo2_kernel'), ('conv3x3_halo3_kernel', 'conv3x3_halo3_kernel'), ('vgg_stem2_kernel', 'vgg_stem2_kernel'),
                  ('gln_transform_batch_kernel', 'gln_transform_batch_kernel'), ('crop_resize2_kernel', 'crop_resize_kernel'), ('crop_resize_kernel', 'crop_resize_kernel'),
                  ('conv1x1_stream_wreg_kernel', 'conv1x1_kernel'), ('conv1x1_stream_kernel', 'conv1x1_kernel'), ('conv1x1_kernel', 'conv1x1_kernel'),
-                 ('thin3x3_kernel', 'thin3x3_kernel'), ('gauss_tail_kernel', 'gauss_tail_kernel')):
+                 ('thin3x3_kernel', 'thin3x3_kernel'), ('gauss_tail_kernel', 'gauss_tail_kernel'), ('gauss_subnet_kernel', 'gauss_subnet_kernel')):
         if k.startswith(p) or k.startswith('void ' + p):
             return n
     return None
