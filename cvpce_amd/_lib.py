@@ -41,6 +41,7 @@ SIGNATURES = {
     'cvpce_conv3x3_halo_wide': (c_int, [_vp, _vp, _fp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_bottleneck_fused': (c_int, [_vp, _vp, _vp, _fp, _vp, _fp, _vp, _fp, _vp] + [c_int] * 11 + [_vp]),
     'cvpce_conv3x3_halo_masked': (c_int, [_vp, _vp, _fp, _vp, _vp, c_int, _vp] + [c_int] * 8 + [_vp]),
+    'cvpce_conv3x3_halo_masked_paired': (c_int, [_vp, _vp, _fp, _vp, _vp, c_int, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_maxpool2d_nhwc_bf16': (c_int, [_vp, _vp] + [c_int] * 9 + [_vp]),
     'cvpce_relu_bf16': (c_int, [_vp, _vp, c_longlong, _vp]),
     'cvpce_pack_halo_weights': (c_int, [_vp, _vp, c_int, c_int]),
@@ -84,7 +85,7 @@ SIGNATURES = {
 # fp16 twins of the detector's kernels (the opt-in accuracy mode): same argument lists as the functions they are named after
 for _base, _twin in (('cvpce_conv2d_nhwc_bf16', 'cvpce_conv2d_nhwc_f16'), ('cvpce_conv2d_splitk_bf16', 'cvpce_conv2d_splitk_f16'), ('cvpce_conv1x1_nhwc_bf16', 'cvpce_conv1x1_nhwc_f16'),
                      ('cvpce_gln_stem_fused', 'cvpce_gln_stem_fused_f16'), ('cvpce_conv3x3_halo', 'cvpce_conv3x3_halo_f16'),
-                     ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_thin_out', 'cvpce_conv3x3_halo_thin_out_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'),
+                     ('cvpce_conv3x3_halo_wide', 'cvpce_conv3x3_halo_wide_f16'), ('cvpce_conv3x3_halo_thin_out', 'cvpce_conv3x3_halo_thin_out_f16'), ('cvpce_conv3x3_halo_masked', 'cvpce_conv3x3_halo_masked_f16'), ('cvpce_conv3x3_halo_masked_paired', 'cvpce_conv3x3_halo_masked_paired_f16'),
                      ('cvpce_bottleneck_fused', 'cvpce_bottleneck_fused_f16'), ('cvpce_bottleneck_fused_fm', 'cvpce_bottleneck_fused_fm_f16'),
                      ('cvpce_maxpool2d_nhwc_bf16', 'cvpce_maxpool2d_nhwc_f16'), ('cvpce_relu_bf16', 'cvpce_relu_f16'), ('cvpce_gauss_tail_bf16', 'cvpce_gauss_tail_f16'), ('cvpce_gauss_subnet_bf16', 'cvpce_gauss_subnet_f16'), ('cvpce_conv3x3_thin_bf16', 'cvpce_conv3x3_thin_f16'),
                      ('cvpce_gln_transform', 'cvpce_gln_transform_f16'), ('cvpce_gln_transform_batch', 'cvpce_gln_transform_batch_f16')):

@@ -78,6 +78,11 @@ struct Halo2Args {
     // entries (device-resident); input pixels with y >= ey_in or x >= ex_in are read from image N - 1 (the constant crop)
     const unsigned long long* list;
     const int* list_count;
+    // PAIRED launches (the RetinaNet head's two towers as ONE launch, cvpce_conv3x3_halo_masked_paired): cout tile ct is tower ct.
+    // in_group_bytes != 0: the input is [towers][N][H][W][Cin] and tile ct reads tower ct's part (0: every tile reads the one input);
+    // out_group_elems != 0: the output is [towers][N][H][W][256] (tower ct's 256 couts of the Cout = 256 x towers), not [N][H][W][Cout]
+    unsigned in_group_bytes;
+    long long out_group_elems;
 };
 
 #if CVPCE_DBG & 512
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv3x3_halo2_kernel
     //      round-robin to the NW waves (wave w: pieces w, w + NW, ...; 41 pieces: 6 for w = 0, else 5 with eight waves) ----
     constexpr int NPP = (41 + NW - 1) / NW;
     const int npp = (41 - wc + NW - 1) / NW;
-    auto issue_patch = [&](const int* n, const int* ty, const int* tx, int c, int buf, const int* ext) {
+    auto issue_patch = [&](const int* n, const int* ty, const int* tx, int c, int buf, const int* ext, int ct) {
         // lane id recomputed here (2 VALU ops, once per patch) instead of living in a VGPR across the K loop; the volatile
         // asm also keeps the per-piece constants below from being hoisted out of the chunk loop (18+ VGPRs)
         int ln;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv3x3_halo2_kernel
                 const bool ok = pp < G2_NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
                 int nn = sn;
                 if constexpr (LIST) nn = (y >= ey || x >= ex) ? a.N - 1 : sn;   // constant region of the crop: the constant crop's pixel
-                const unsigned off = (unsigned)((((size_t)(nn * a.H + y) * a.W + x) * a.Cin + c * 64) * 2) + (unsigned)(lchunk * 16);
+                const unsigned off = (unsigned)((((size_t)(nn * a.H + y) * a.W + x) * a.Cin + c * 64) * 2) + (unsigned)(lchunk * 16) + (unsigned)ct * a.in_group_bytes;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_p, (lds_void*)(Ap + buf * G2_A_BYTES + j * 1024), 16,
                                                          (int)(ok ? off : 0xFFFFFFF0u), 0, 0, 0);
             }
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv3x3_halo2_kernel
     tile_of(0, pi_n, pi_ty, pi_tx, pi_ct, pi_ext);
     auto issue_next_patch = [&]() {
         if (pi < total_chunks) {
-            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf, pi_ext);
+            if (!(CVPCE_DBG & 4) || pi < 2) issue_patch(pi_n, pi_ty, pi_tx, pi_c, pi_buf, pi_ext, pi_ct);
             ++pi;
             if (++pi_buf == 3) pi_buf = 0;
             if (++pi_c == nchunks) {
@@ -560,7 +565,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv3x3_halo2_kernel
                     }
                     if (store_lane && co < a.Cout && (!(CVPCE_DBG & 16) || a.relu == 12345)) {
                         const uint2 l2 = __builtin_bit_cast(uint2, E::pack4(r0)), h2 = __builtin_bit_cast(uint2, E::pack4(r1));
-                        *reinterpret_cast<u32x4*>(a.out + opix * a.Cout + co) = keep ? u32x4{l2.x, l2.y, h2.x, h2.y} : u32x4{0u, 0u, 0u, 0u};
+                        bf16_t* dst = a.out_group_elems ? a.out + (size_t)ct * a.out_group_elems + opix * TC + (co - ct * TC) : a.out + opix * a.Cout + co;
+                        *reinterpret_cast<u32x4*>(dst) = keep ? u32x4{l2.x, l2.y, h2.x, h2.y} : u32x4{0u, 0u, 0u, 0u};
                     }
                 }
             }
@@ -630,7 +636,7 @@ template <typename E>
 static int halo2_dispatch(const void* in, const void* wgt, const float* bias, const unsigned char* mask, const int* tile_map,
                           int n_map, void* out, float* gmax,
                           int gmax_stride, int gmax_off, int N, int H, int W, int Cin, int Cout, int K_pad, int Cout_pad, int relu,
-                          int fuse_pool2, void* stream) {
+                          int fuse_pool2, void* stream, int paired = 0) {
     if (N <= 0) return CVPCE_OK;
     if (!in || !wgt || (!out && !gmax)) return CVPCE_ERR_ARG;
     if (gmax && (!relu || mask || Cout <= 128 || gmax_off < 0 || gmax_off + Cout > gmax_stride)) return CVPCE_ERR_ARG;
@@ -657,6 +663,19 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;
     a.list = nullptr; a.list_count = nullptr;
+    a.in_group_bytes = 0; a.out_group_elems = 0;
+    if (paired) {
+        // the two (or more) towers as cout tiles of one launch: Cout = 256 x towers, the output tower-major; the input tower-major too
+        // (paired == 2) or one tensor every tower reads (paired == 1: the towers' first layer on the level atlas)
+        if (!mask || gmax || fuse_pool2 || Cout % 256 != 0 || Cout < 512) return CVPCE_ERR_ARG;
+        const long long towers = Cout / 256;
+        if ((long long)N * H * W * Cin * 2 * (paired == 2 ? towers : 1) >= (1LL << 32)) return CVPCE_ERR_ARG;
+        a.out_group_elems = (long long)N * H * W * 256;
+        if (paired == 2) {
+            a.in_group_bytes = (unsigned)((long long)N * H * W * Cin * 2);
+            a.in_bytes = (unsigned)((long long)N * H * W * Cin * 2 * towers);
+        }
+    }
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (gmax) return fuse_pool2 ? launch_halo2<E, true, true>(a, s) : launch_halo2<E, false, true>(a, s);
@@ -674,6 +693,10 @@ static int halo2_dispatch(const void* in, const void* wgt, const float* bias, co
             b.out = a.out + (size_t)n0 * H * W * Cout;
             b.ptiles = b.N * a.tiles_per_image;
             b.in_bytes = (unsigned)((long long)b.N * H * W * Cin * 2);
+            if (a.out_group_elems) {                                 // tower-major tensors: the towers' parts keep the whole batch's strides
+                b.out = a.out + (size_t)n0 * H * W * 256;
+                if (a.in_group_bytes) b.in_bytes = a.in_bytes - (unsigned)((long long)n0 * H * W * Cin * 2);
+            }
             const int rc = launch_halo2<E, false, false>(b, s);
             if (rc != CVPCE_OK) return rc;
         }
@@ -699,6 +722,19 @@ extern "C" int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const 
                                          int K_pad, int Cout_pad, int relu, void* stream) {
     if (!mask) return CVPCE_ERR_ARG;
     return halo2_dispatch<ElemBF16>(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream);
+}
+
+extern "C" int cvpce_conv3x3_halo_masked_paired(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                                const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout,
+                                                int K_pad, int Cout_pad, int relu, int in_paired, void* stream) {
+    if (!mask) return CVPCE_ERR_ARG;
+    return halo2_dispatch<ElemBF16>(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream, in_paired ? 2 : 1);
+}
+extern "C" int cvpce_conv3x3_halo_masked_paired_f16(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                                    const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout,
+                                                    int K_pad, int Cout_pad, int relu, int in_paired, void* stream) {
+    if (!mask) return CVPCE_ERR_ARG;
+    return halo2_dispatch<ElemF16>(in, wgt, bias, mask, tile_map, n_tiles, out, nullptr, 0, 0, N, H, W, Cin, Cout, K_pad, Cout_pad, relu, 0, stream, in_paired ? 2 : 1);
 }
 
 // fp16 twins (the detector's accuracy mode; same contracts, element type fp16)
@@ -746,6 +782,7 @@ static int halo_list_launch(const void* in, const void* wgt, const float* bias, 
     a.wgt_bytes = (unsigned)((long long)Cout_pad * K_pad * 2);
     a.ctiles = a.ntiles = 0;
     a.list = list; a.list_count = count_dev;
+    a.in_group_bytes = 0; a.out_group_elems = 0;
     if ((long long)a.ptiles * ((Cout + 255) / 256) * (Cin / 64) >= (1LL << 30)) return CVPCE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (strips) {

@@ -38,6 +38,7 @@ CAPTURE_ON_SIGHT = 2      # a geometry is captured on its 2nd call (the 1st runs
 MAX_CAPTURE_ON_SIGHT = 16  # ... and later, up to this many sights, once captured graphs start being evicted barely used (many geometries)
 MAX_SIGHT_COUNTS = 512    # geometries whose call counts are remembered (LRU)
 USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
+USE_PAIRED_TOWERS = os.environ.get('CVPCE_PAIRED_TOWERS', '1') != '0'   # A/B switch: layer i of both head towers in one masked launch
 USE_ATLAS_COPY = os.environ.get('CVPCE_ATLAS_COPY', '1') != '0'       # levels <-> atlas in one launch each way (15 slice copies otherwise)
 USE_BATCHED_TRANSFORM = os.environ.get('CVPCE_BATCHED_TRANSFORM', '1') != '0'   # the input transform of a whole batch in one launch
 USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
@@ -274,6 +275,12 @@ class GLNEngine:
         self.cls_out = P(ch.cls_logits)
         self.reg_tower = [P(rh.conv[i]) for i in (0, 2, 4, 6)]
         self.reg_out = P(rh.bbox_reg)
+        # layer i of BOTH towers as one conv with Cout = 512 (cout tile 0 = the classification tower, 1 = the regression tower): one masked
+        # launch per layer instead of two (ops.conv3x3_atlas_paired)
+        self.tower_pairs = None
+        if USE_PAIRED_TOWERS and all(c.out_channels == 256 and c.in_channels == 256 for i in (0, 2, 4, 6) for c in (ch.conv[i], rh.conv[i])):
+            self.tower_pairs = [ops.PackedConv(torch.cat((ch.conv[i].weight, rh.conv[i].weight)), torch.cat((ch.conv[i].bias, rh.conv[i].bias)), 1, 1,
+                                               device=device, dtype=self.dtype) for i in (0, 2, 4, 6)]
         self.base_anchors = _base_anchors().to(device)
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(4)] if N_SIDE_STREAMS else []
         self.num_anchors = self.base_anchors.shape[1]
@@ -435,18 +442,43 @@ class GLNEngine:
         # the tiles they compute) and skip the tiles that lie wholly in a gap, so the gaps stay zero -- no memset, and about
         # 1/7 of the canvas tiles (the empty ones) are never scheduled.
         bufs = self.__dict__.setdefault('_atlas_bufs', {})
-        bkey = (n, hc, wc)
+        bkey = (n, hc, wc, self.tower_pairs is not None)
         if bkey not in bufs:
             if len(bufs) >= MAX_DETECT_GRAPHS:
                 bufs.pop(next(iter(bufs)))
-            bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=self.dtype, device=self.device) for _ in range(5)]
-        atlas, cls_a, cls_b, reg_a, reg_b = bufs[bkey]
+            bufs[bkey] = [torch.zeros(n, hc, wc, FPN_CHANNELS, dtype=self.dtype, device=self.device) for _ in range(1 if self.tower_pairs is not None else 5)]
+        atlas, cls_a, cls_b, reg_a, reg_b = (bufs[bkey] + [None] * 4)[:5]
         self._keep(bufs[bkey])
         if USE_ATLAS_COPY:
             ops.atlas_pack(feats, atlas, offs)               # the five levels into the canvas, one launch
         else:
             for f, (h, w), (oy, ox) in zip(feats, shapes, offs):
                 atlas[:, oy:oy + h, ox:ox + w] = f
+
+        def finish(t, final):
+            o = ops.conv2d(t, final, out_f32=True)           # gap pixels hold junk here; they are never read
+            if USE_ATLAS_COPY:
+                return ops.atlas_unpack(o, shapes, offs)
+            return [o[:, oy:oy + h, ox:ox + w].contiguous() for (h, w), (oy, ox) in zip(shapes, offs)]
+
+        if self.tower_pairs is not None:
+            # both towers, layer by layer, in ONE launch each: 2 x 284 tiles in three rounds of the persistent grid instead of 2 + 2
+            pk = ('pair', n, hc, wc)
+            if pk not in bufs:
+                bufs[pk] = [torch.zeros(2, n, hc, wc, FPN_CHANNELS, dtype=self.dtype, device=self.device) for _ in range(2)]
+            ping, pong = bufs[pk]
+            self._keep(bufs[pk])
+            t = atlas
+            for i, pc in enumerate(self.tower_pairs):
+                t = ops.conv3x3_atlas_paired(t, pc, mask, act=1, tile_map=tile_map, out=ping, mask_pixels=npix, in_paired=i > 0)
+                ping, pong = pong, ping
+            if not self.side_streams:
+                return finish(t[0], self.cls_out), finish(t[1], self.reg_out)
+            (reg), reg_done = self._beside(0, lambda: tuple(finish(t[1], self.reg_out)))
+            cls = finish(t[0], self.cls_out)
+            if reg_done is not None:
+                torch.cuda.current_stream().wait_event(reg_done)
+            return cls, list(reg)
 
         def chain(tower, final, ping, pong):
             t = atlas

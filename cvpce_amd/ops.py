@@ -529,6 +529,35 @@ def conv3x3_atlas(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None)
     return out
 
 
+def conv3x3_atlas_paired(x, pc, mask, act=1, tile_map=None, out=None, mask_pixels=None, in_paired=False):
+    """Layer i of the head's TWO towers (torchvision RetinaNetHead) as ONE masked launch: `pc` packs the towers' layer-i weights
+    concatenated along Cout (256 x towers); x is one atlas (N,H,W,Cin) every tower reads (in_paired=False: the first layer) or the
+    tower-major output of the previous paired launch (towers,N,H,W,Cin); -> (towers,N,H,W,256), tower t's output in part t."""
+    _need_cuda(x, mask, tile_map, out)
+    towers = pc.cout // 256
+    assert pc.cout == 256 * towers and towers >= 2 and x.dtype == pc.dtype and x.is_contiguous() and mask.dtype == torch.uint8 and mask.is_contiguous()
+    n, h, w, cin = x.shape[-4:]
+    assert tuple(x.shape) == ((towers, n, h, w, cin) if in_paired else (n, h, w, cin))
+    assert tuple(mask.shape) == (h, w) and cin == pc.cin_pad and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1) and pc.cin_pad % 64 == 0 and act in (0, 1)
+    if tile_map is not None:
+        assert out is not None and tile_map.dtype == torch.int32 and tile_map.is_contiguous()
+    if out is None:
+        out = torch.empty((towers, n, h, w, 256), dtype=x.dtype, device=x.device)
+    assert tuple(out.shape) == (towers, n, h, w, 256) and out.dtype == x.dtype and out.is_contiguous()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    T.conv3x3_halo_masked_paired(x, pc.weight_halo, pc.bias, mask, tile_map, out, pc.cout, pc.k_pad, pc.cout_pad, int(act), int(bool(in_paired)))
+    if prof is not None:
+        e1.record()
+        npix = float(mask.sum().item()) if mask_pixels is None else float(mask_pixels)
+        prof.records.append(('conv3x3_halo2_kernel', 2.0 * npix * n * pc.cout * 9 * pc.cin, e0, e1))
+        prof.layer(f'conv3x3_halo2 atlas {pc.cin}->{towers}x256 (both head towers)', 2.0 * npix * n * pc.cout * 9 * pc.cin,
+                   2 * npix * n * ((towers if in_paired else 1) * pc.cin + pc.cout) * x.element_size() + _nbytes(pc.weight), e0, e1)
+    return out
+
+
 def atlas_pack(levels, atlas, offs):
     """levels[l] (N,h,w,C) -> atlas[:, oy:oy+h, ox:ox+w] for every level, one launch."""
     _need_cuda(atlas, *levels)

@@ -109,6 +109,18 @@ def _conv3x3_halo_mac(x, weight, bias, out, mac, mac_off, cout, k_pad, cout_pad,
                                      cout_pad, pool, _stream()), 'cvpce_conv3x3_halo_mac')
 
 
+@_op('conv3x3_halo_masked_paired(Tensor x, Tensor weight, Tensor? bias, Tensor mask, Tensor? tile_map, Tensor(a!) out, int cout, int k_pad, '
+     'int cout_pad, int relu, int in_paired) -> ()')
+def _conv3x3_halo_masked_paired(x, weight, bias, mask, tile_map, out, cout, k_pad, cout_pad, relu, in_paired):
+    towers = cout // 256
+    n, h, w, cin = x.shape[-4:]
+    assert cout == 256 * towers and towers >= 2 and tuple(out.shape) == (towers, n, h, w, 256)
+    assert tuple(x.shape) == ((towers, n, h, w, cin) if in_paired else (n, h, w, cin))
+    fn = _by_dtype(x, 'cvpce_conv3x3_halo_masked_paired', 'cvpce_conv3x3_halo_masked_paired_f16', weight, out)
+    check(fn(_p(x), _p(weight), _p(bias), _p(mask), _p(tile_map), tile_map.numel() if tile_map is not None else 0,
+             _p(out), n, h, w, cin, cout, k_pad, cout_pad, relu, in_paired, _stream()), 'cvpce_conv3x3_halo_masked_paired')
+
+
 @_op('conv3x3_halo_masked(Tensor x, Tensor weight, Tensor? bias, Tensor mask, Tensor? tile_map, Tensor(a!) out, int cout, int k_pad, '
      'int cout_pad, int relu) -> ()')
 def _conv3x3_halo_masked(x, weight, bias, mask, tile_map, out, cout, k_pad, cout_pad, relu):

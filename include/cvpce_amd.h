@@ -137,6 +137,18 @@ int cvpce_conv3x3_halo_masked(const void* in, const void* wgt, const float* bias
                               const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
                               int Cout_pad, int relu, void* stream);
 
+/* cvpce_conv3x3_halo_masked for the head's TWO towers in one launch (torchvision RetinaNetHead: classification_head.conv and
+ * regression_head.conv are two independent chains of four 3x3 256 -> 256 convs + ReLU over the same features; reached from
+ * cvpce/models/proposals.py:166).  Layer i of both towers = one conv with Cout = 256 x towers whose cout tile t is tower t:
+ * wgt / bias = the towers' layer-i weights concatenated along Cout (fragment-major halo layout of the [Cout][9 Cin] matrix);
+ * in_paired = 0: `in` is ONE atlas [N][H][W][Cin] every tower reads (the first layer); in_paired = 1: `in` is tower-major
+ * [towers][N][H][W][Cin], tile t reads part t (the later layers).  `out` is ALWAYS tower-major [towers][N][H][W][256]: part t is
+ * tower t's layer-i output, a valid atlas for the next paired launch and contiguous for the tower's output conv.  One launch has
+ * towers x the tiles of a per-tower launch on the same persistent grid: 568 tiles in three rounds instead of 2 x (284 in two). */
+int cvpce_conv3x3_halo_masked_paired(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                     const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
+                                     int Cout_pad, int relu, int in_paired, void* stream);
+
 /* One ResNet-50 bottleneck block (torchvision `Bottleneck`, v1.5, STRIDE 1, FrozenBatchNorm2d folded into weights and biases;
  * reached from cvpce/models/proposals.py:202-216) in one launch, the two P-channel intermediates held in LDS:
  *   out = relu( conv1x1_w3( relu( conv3x3_w2( relu( conv1x1_w1(x) + b1 ) ) + b2 ) ) + b3 + res )
@@ -377,6 +389,9 @@ int cvpce_conv3x3_halo_f16(const void* in, const void* wgt, const float* bias, v
                            int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
 int cvpce_conv3x3_halo_wide_f16(const void* in, const void* wgt, const float* bias, void* out, int N, int H, int W, int Cin,
                                 int Cout, int K_pad, int Cout_pad, int relu, int fuse_pool2, void* stream);
+int cvpce_conv3x3_halo_masked_paired_f16(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
+                                         const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
+                                         int Cout_pad, int relu, int in_paired, void* stream);
 int cvpce_conv3x3_halo_masked_f16(const void* in, const void* wgt, const float* bias, const unsigned char* mask,
                                   const int* tile_map, int n_tiles, void* out, int N, int H, int W, int Cin, int Cout, int K_pad,
                                   int Cout_pad, int relu, void* stream);

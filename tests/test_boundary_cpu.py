@@ -44,13 +44,13 @@ def test_torch_ops_registered_for_the_gpu_only():
     # the fp16 twins of the detector's kernels (round 3) are reached through the SAME ops: the op picks the entry point by the
     # activations' dtype (torch_ops._by_dtype) -- every twin must have its bf16 original declared too
     twins = {s for s in declared if s.endswith('_f16')}
-    assert len(twins) == 16
+    assert len(twins) == 18      # (round 6: + the fused Gaussian subnet, the paired head-tower launch)
     for t in twins:
         base = t[:-4]
         assert base in declared or base + '_bf16' in declared, t
     declared -= twins
     # (the two 3x3 halo entry points share one op: Cout <= 128 is forwarded to the wide-tile kernel inside the library)
-    assert len(torch_ops.NAMES) == len(declared) == 38   # (round 5: + the head's thin-output 3x3, the fragment-major bottleneck, the split-K form of the register-staged conv, the content-only crop) (two halo entry points share an op; atlas_copy has two; round 4: the seven work-list / extent / MAC-start entry points, the Gaussian subnet's tail and its thin 3x3 layers; round 5: the matcher's one-launch form and its state initialiser)
+    assert len(torch_ops.NAMES) == len(declared) == 40   # (round 6: + gauss_subnet, conv3x3_halo_masked_paired) (round 5: + the head's thin-output 3x3, the fragment-major bottleneck, the split-K form of the register-staged conv, the content-only crop) (two halo entry points share an op; atlas_copy has two; round 4: the seven work-list / extent / MAC-start entry points, the Gaussian subnet's tail and its thin 3x3 layers; round 5: the matcher's one-launch form and its state initialiser)
     for name in torch_ops.NAMES:
         op = getattr(torch.ops.cvpce_amd, name)
         assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'cvpce_amd::{name}', 'CPU')

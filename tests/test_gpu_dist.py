@@ -33,11 +33,18 @@ def _bench(world, images_per_gpu, self_launch=False, extra_env=None):
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
                '--master-port', str(_free_port())] + tail
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
-    return json.loads(lines[0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        det = os.path.join(tmp, 'details.json')
+        r = subprocess.run(cmd + ['--details', det], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
+        assert len(lines[0]) < 4096
+        line, full = json.loads(lines[0]), json.load(open(det))
+    # the compact line carries the job digest and the world size the process group saw; the per-image digests are in the details file
+    assert line['verify'] == {'images': full['verify']['images'], 'digest': full['verify']['digest']} and line['value'] == full['value']
+    return full
 
 
 def test_bench_two_ranks_bit_identical_to_one_rank(cuda):

@@ -9,7 +9,10 @@ tag=$1
 R=$PWD; O=$R/gpurun_out; B=$R/bench.py
 cd /tmp; export TMPDIR=/tmp
 if [ -z "$SKIP_STATS" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $B --steps 5 --warmup 2 > $O/prof_$tag.log 2>&1
+# (the stats pass runs the headline steps and the roofline leg ONLY -- no lists-off / planted-box / fitted-scene / precision legs, which launch
+#  the same template instances on other work: every LIST / STRIP launch in the CSV is then a launch of the headline step, and
+#  tools/roofline_check.py can reproduce `roofline.achieved` from the CSV and the details file alone)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $B --steps 5 --warmup 2 --no-coheadlines --no-workloads --no-parity --no-cpu-baseline --no-precision-leg --no-h2d --no-peaks --no-clocks --details $O/prof_${tag}_details.json > $O/prof_$tag.log 2>&1
 echo "stats pass done"
 fi
 # (the counter passes end with ONE headline step: every side leg off, so that "the last pipeline pass" of the trace is that step)

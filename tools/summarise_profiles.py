@@ -5,11 +5,34 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, prof, pmc = sys.argv[1], sys.argv[2], sys.argv[3]          # e.g. r01g prof_r1g pmc7
 
 
+def short_name(k):
+    """a rocprof kernel name without `void ` and the argument list, the template arguments kept WHOLE: round 5 cut names at 46 characters
+    and merged the LIST, STRIP and plain instances of conv3x3_halo2_kernel (three different kernels) into one row."""
+    k = k[5:] if k.startswith('void ') else k
+    depth = 0
+    for i, ch in enumerate(k):
+        depth += ch == '<'
+        depth -= ch == '>'
+        if ch == '(' and depth == 0:
+            return k[:i]
+    return k
+
+
+def template_args(k):
+    k = short_name(k)
+    return [a.strip() for a in k[k.index('<') + 1:k.rindex('>')].split(',')] if '<' in k else []
+
+
 def prof_name(k):    # rocprof kernel name -> the name ops.ConvProfile / bench.py use (roofline.traffic, roofline.hbm_stages)
     # the detector (fp16 storage by default) runs ElemF16 instances of the 3x3 halo kernels: filed apart, like bench.py's profile does
     for p in ('conv3x3_halo2_kernel', 'conv3x3_halo3_kernel'):
         if (k.startswith(p) or k.startswith('void ' + p)) and 'ElemF16' in k:
             return p + '[detector]'
+    # conv3x3_halo2_kernel<E, POOL, GMAX, LIST, STRIP, NW>: the STRIP instances are launches of their own (bench.py files them apart too)
+    if k.startswith('void conv3x3_halo2_kernel') or k.startswith('conv3x3_halo2_kernel'):
+        ta = template_args(k)
+        if len(ta) >= 5 and ta[4] == 'true':
+            return 'conv3x3_halo2_kernel[strips]'
     for p, n in (('conv3x3_halo2_kernel', 'conv3x3_halo2_kernel'), ('conv3x3_halo3_kernel', 'conv3x3_halo3_kernel'), ('vgg_stem2_kernel', 'vgg_stem2_kernel'),
                  ('gln_transform_batch_kernel', 'gln_transform_batch_kernel'), ('crop_resize2_kernel', 'crop_resize_kernel'), ('crop_resize_kernel', 'crop_resize_kernel'),
                  ('conv1x1_stream_wreg_kernel', 'conv1x1_kernel'), ('conv1x1_stream_kernel', 'conv1x1_kernel'), ('conv1x1_kernel', 'conv1x1_kernel'),
@@ -48,7 +71,7 @@ with open(f'{root}/profiles/{tag}_pmc_hbm_traffic.md', 'w') as fo:
     fo.write('FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of wide reads at 64 B); WRITE_SIZE as is.\n\n')
     fo.write('| kernel | launches | read MB/launch | write MB/launch | total MB/launch |\n|---|---|---|---|---|\n')
     for k, n, fb, wb in rows[:14]:
-        fo.write(f'| `{k[:70]}` | {n} | {fb / 1e6:.1f} | {wb / 1e6:.1f} | {(fb + wb) / 1e6:.1f} |\n')
+        fo.write(f'| `{short_name(k)}` | {n} | {fb / 1e6:.1f} | {wb / 1e6:.1f} | {(fb + wb) / 1e6:.1f} |\n')
     for k, n, fb, wb in rows:
         pn = prof_name(k)
         if pn:
@@ -69,7 +92,7 @@ for kind in ('sq', 'tcc'):
     dur = {r['Dispatch_Id']: int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(kt))}
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'][:46]
+        k = short_name(r['Kernel_Name'])
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
         if kind == 'sq' and r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
             agg[k]['_dur'].append(dur[r['Dispatch_Id']])
