@@ -38,7 +38,10 @@ CAPTURE_ON_SIGHT = 2      # a geometry is captured on its 2nd call (the 1st runs
 MAX_CAPTURE_ON_SIGHT = 16  # ... and later, up to this many sights, once captured graphs start being evicted barely used (many geometries)
 MAX_SIGHT_COUNTS = 512    # geometries whose call counts are remembered (LRU)
 USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
-USE_PAIRED_TOWERS = os.environ.get('CVPCE_PAIRED_TOWERS', '1') != '0'   # A/B switch: layer i of both head towers in one masked launch
+# opt-in: layer i of both head towers in one masked launch (568 tiles in three rounds of the persistent grid).  Built, bit-identical, NOT faster:
+# the two towers' launches already run beside each other on two streams and share the grid's second round (configs[1], same call: 2.475 ms
+# per-tower vs 2.509 ms paired; profiles/r06_rejected_experiments.md)
+USE_PAIRED_TOWERS = os.environ.get('CVPCE_PAIRED_TOWERS', '0') != '0'
 USE_ATLAS_COPY = os.environ.get('CVPCE_ATLAS_COPY', '1') != '0'       # levels <-> atlas in one launch each way (15 slice copies otherwise)
 USE_BATCHED_TRANSFORM = os.environ.get('CVPCE_BATCHED_TRANSFORM', '1') != '0'   # the input transform of a whole batch in one launch
 USE_FUSED_STEM = os.environ.get('CVPCE_FUSED_GLN_STEM', '1') != '0'     # conv1 + bn1 + relu + maxpool in one launch (csrc/gln_stem.hip); False: generic conv + pool kernels
@@ -277,14 +280,20 @@ class GLNEngine:
         self.reg_out = P(rh.bbox_reg)
         # layer i of BOTH towers as one conv with Cout = 512 (cout tile 0 = the classification tower, 1 = the regression tower): one masked
         # launch per layer instead of two (ops.conv3x3_atlas_paired)
-        self.tower_pairs = None
-        if USE_PAIRED_TOWERS and all(c.out_channels == 256 and c.in_channels == 256 for i in (0, 2, 4, 6) for c in (ch.conv[i], rh.conv[i])):
-            self.tower_pairs = [ops.PackedConv(torch.cat((ch.conv[i].weight, rh.conv[i].weight)), torch.cat((ch.conv[i].bias, rh.conv[i].bias)), 1, 1,
-                                               device=device, dtype=self.dtype) for i in (0, 2, 4, 6)]
+        self.tower_pairs = self.pack_tower_pairs(model, device) if USE_PAIRED_TOWERS else None
         self.base_anchors = _base_anchors().to(device)
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(4)] if N_SIDE_STREAMS else []
         self.num_anchors = self.base_anchors.shape[1]
         self.device = device
+
+    def pack_tower_pairs(self, model, device=None):
+        """Layer i of BOTH head towers as one conv with Cout = 512 (cout tile 0 = the classification tower, 1 = the regression tower), for
+        `ops.conv3x3_atlas_paired`; None when the towers are not 4 x (256 -> 256)."""
+        ch, rh = model.head.classification_head, model.head.regression_head
+        if not all(c.out_channels == 256 and c.in_channels == 256 for i in (0, 2, 4, 6) for c in (ch.conv[i], rh.conv[i])):
+            return None
+        return [ops.PackedConv(torch.cat((ch.conv[i].weight, rh.conv[i].weight)), torch.cat((ch.conv[i].bias, rh.conv[i].bias)), 1, 1,
+                               device=device if device is not None else self.device, dtype=self.dtype) for i in (0, 2, 4, 6)]
 
     def pack_gaussian(self, gl, subnet, device, dtype=None):
         """Gaussian branch weights (proposals.py:65-107): eval-mode BatchNorm folded into block1/block2."""

@@ -371,14 +371,15 @@ def test_head_atlas_equals_per_level(cuda, gln_model, hw):
     for a, b in zip(cls_a + reg_a, cls_l + reg_l):
         assert a.shape == b.shape
         assert (a - b).abs().max() <= 0.02 * b.abs().max() + 1e-3, ((a - b).abs().max(), b.abs().max())
-    # round 6: `heads_atlas` runs layer i of BOTH towers as one paired launch (the towers as cout tiles of one conv); the per-tower
-    # launches compute every tile with the same arithmetic, so the two forms agree bit for bit
-    assert eng.tower_pairs is not None
-    pairs, eng.tower_pairs = eng.tower_pairs, None
+    # round 6: layer i of BOTH towers as one paired launch (the towers as cout tiles of one conv; opt-in, CVPCE_PAIRED_TOWERS=1): every
+    # tile is computed with the same arithmetic as in the per-tower launches, so the two forms agree bit for bit
+    assert eng.tower_pairs is None
+    eng.tower_pairs = eng.pack_tower_pairs(model)
+    assert eng.tower_pairs is not None and eng.tower_pairs[0].cout == 512
     try:
         cls_u, reg_u = eng.heads_atlas(feats)
     finally:
-        eng.tower_pairs = pairs
+        eng.tower_pairs = None
     torch.cuda.synchronize()
     for a, b in zip(cls_a + reg_a, cls_u + reg_u):
         assert torch.equal(a, b)
