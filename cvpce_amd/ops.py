@@ -163,6 +163,18 @@ class ConvProfile:
         tc = 128 if pc.cout > 64 else (32 if (pc.cout <= 32 and bk64) else 64)
         return f'conv_igemm_kernel<{tc},128,{64 if bk64 else 32},{1 if tc == 32 else 2},{4 if tc == 32 else 2}>'
 
+    @staticmethod
+    def is_igemm128(pc, m):
+        """whether `variant(pc, m)` is the 128-cout register-staged kernel (the one with a split-K form), without formatting a name on the
+        launch path."""
+        if pc.cout <= 64:
+            return False
+        if pc.cin_pad % 64 == 0 and not FORCE_GENERIC_CONV:
+            tiles256 = (m + 255) // 256
+            if (pc.cout >= 192 and tiles256 * ((pc.cout + 255) // 256) >= 128) or (pc.cout <= 128 and tiles256 >= 128):
+                return False
+        return True
+
     def summary(self):
         """per kernel: launches, algorithmic FLOPs (`flops`), EXECUTED FLOPs (`flops_executed`: work-list launches of the embedder
         compute only the tiles on their list -- records carry (device count, FLOPs per listed tile) for those), milliseconds."""
@@ -281,13 +293,24 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
         return out
     # small maps with a long K (layer4's 3x3 convs on 25 x 25 maps, the stride-2 3x3s that open layer3 / layer4, P5 / P6 / P7): the
     # register-staged kernel with K split over `ks` workgroups per output tile (csrc/conv_igemm.hip SPLIT)
-    ks = splitk_factor(pc, ho, wo) if (not pool and not FORCE_GENERIC_CONV and ConvProfile.variant(pc, n * ho * wo).startswith('conv_igemm_kernel<128')) else 0
+    ks = splitk_factor(pc, ho, wo) if (not pool and not FORCE_GENERIC_CONV and ConvProfile.is_igemm128(pc, n * ho * wo)) else 0
+    ws = None
     if ks:
-        cache = pc.__dict__.setdefault('_splitk_ws', {})        # one workspace per launch shape, never freed (captured graphs hold its address)
-        key = (n, ho, wo, ks, x.device)
+        # one fp32 workspace per (launch shape, device, STREAM): two streams running this layer at once must not share partial sums.  Captured
+        # graphs hold a workspace's address, so entries are never freed while they may be replayed; the cache is bounded by evicting the
+        # oldest entry only outside a capture, and a shape first seen DURING a capture takes the unsplit kernel (no allocation from the
+        # graph's private pool)
+        cache = pc.__dict__.setdefault('_splitk_ws', {})
+        key = (n, ho, wo, ks, x.device, torch.cuda.current_stream(x.device).cuda_stream)
         ws = cache.get(key)
         if ws is None:
-            ws = cache[key] = torch.empty(int(lib.cvpce_conv2d_splitk_workspace_bytes(n * ho * wo, pc.cout, ks)), dtype=torch.uint8, device=x.device)
+            if torch.cuda.is_current_stream_capturing():
+                ks = 0
+            else:
+                if len(cache) >= SPLITK_WS_MAX:
+                    cache.pop(next(iter(cache)))
+                ws = cache[key] = torch.empty(int(lib.cvpce_conv2d_splitk_workspace_bytes(n * ho * wo, pc.cout, ks)), dtype=torch.uint8, device=x.device)
+    if ks:
         T.conv2d_splitk(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
                         int(act), int(out_f32), int(in_up_shift), int(res_mode), ks, ws)
     else:
@@ -303,6 +326,7 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
 
 
 CONV_SPLITK = _os.environ.get('CVPCE_CONV_SPLITK', '1') != '0'   # A/B switch: split-K launches of the register-staged kernel
+SPLITK_WS_MAX = 16      # split-K workspaces kept per layer (launch shape x stream): windows of 1-8 images of a few geometries
 
 
 def splitk_factor(pc, ho, wo):
@@ -968,7 +992,7 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
     dist = torch.empty((qn, k), dtype=torch.float32, device=queries.device) if return_distance else None
     ws_bytes = lib.cvpce_match_workspace_bytes(qn, gn, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=queries.device)
-    if k == 1 and queries.dtype == BF16 and qn <= MATCH_STATE_QUERIES and (_match_state_key(queries.device) in _MATCH_STATE or not torch.cuda.is_current_stream_capturing()):
+    if MATCH_ONE_LAUNCH and k == 1 and queries.dtype == BF16 and qn <= MATCH_STATE_QUERIES and (_match_state_key(queries.device) in _MATCH_STATE or not torch.cuda.is_current_stream_capturing()):
         # the one-launch form: a state block per (device, stream) -- launches of one stream are ordered, so they can share a block
         T.match_topk_state(queries, gallery, q_norms, g_norms, k, ws, match_state(queries.device), idx, dist)
     else:
@@ -978,6 +1002,20 @@ def match_topk(queries, gallery, k=1, q_norms=None, g_norms=None, return_distanc
 
 MATCH_STATE_QUERIES = 16384      # queries per launch the one-launch top-1 search holds keys for (128 KiB per state block)
 _MATCH_STATE = {}
+# The one-launch form of the k = 1 search is an opt-in (measured slower than two launches, profiles/r05_rejected_experiments.md): only
+# when it is on does a launch get a state block (128 KiB per device and stream) and go through cvpce_match_topk_state.  A hipGraph
+# captured with it on must be replayed on its capture stream: the block belongs to that stream's launch order.
+MATCH_ONE_LAUNCH = _os.environ.get('CVPCE_MATCH_FUSED', '0') not in ('', '0')
+
+
+def match_set_core(core=0, nq=0, mg=0, one_launch=0):
+    """`cvpce_match_set_core` (include/cvpce_amd.h): pin the bf16 search's core / tile (0 = the cost model's choice) and switch the
+    one-launch form of k = 1 on or off -- here AND in this module's dispatch.  -> the library's status (0 = ok)."""
+    global MATCH_ONE_LAUNCH
+    rc = int(lib.cvpce_match_set_core(int(core), int(nq), int(mg), int(one_launch)))
+    if rc == 0:
+        MATCH_ONE_LAUNCH = bool(one_launch)
+    return rc
 
 
 def _match_state_key(device):

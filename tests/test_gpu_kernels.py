@@ -586,7 +586,8 @@ def test_match_every_core_and_tile_gives_identical_results(cuda, qn, gn, d):
     ref = None
     try:
         for core, nq, mg, one in variants:
-            assert lib.cvpce_match_set_core(core, nq, mg, one) == 0
+            assert ops.match_set_core(core, nq, mg, one) == 0
+            assert ops.MATCH_ONE_LAUNCH == bool(one)
             got = [ops.match_topk(Qd, Gd, 4, return_distance=True), ops.match_topk(Qd, Gd, 1, return_distance=True),
                    ops.match_topk(Qd, Gd, 1, return_distance=True)]
             torch.cuda.synchronize()
@@ -599,7 +600,8 @@ def test_match_every_core_and_tile_gives_identical_results(cuda, qn, gn, d):
                 assert i.equal(ri), (core, nq, mg, one)
                 assert torch.equal(x.view(torch.int32), rx.view(torch.int32)), (core, nq, mg, one)       # bit for bit (inf rows included)
     finally:
-        lib.cvpce_match_set_core(0, 0, 0, 0)
+        ops.match_set_core(0, 0, 0, 0)
+    assert not ops._MATCH_STATE or ops.MATCH_ONE_LAUNCH is False          # (a state block exists only because a one-launch variant ran)
     assert ref[0][0][1].tolist() == [0, 1, 2, 3]                                      # the NaN query: all distances +inf, lowest rows first
     assert lib.cvpce_match_set_core(2, 5, 1, 0) == 1 and lib.cvpce_match_set_core(3, 0, 0, 0) == 1      # no 128-row x 320-query tile; no such core
 

@@ -385,6 +385,27 @@ def test_head_atlas_equals_per_level(cuda, gln_model, hw):
         assert torch.equal(a, b)
 
 
+def test_detection_does_not_depend_on_the_batch(cuda):
+    """the detector's generic convs pick their kernel (LDS-DMA, register-staged, split-K) by N * Ho * Wo inside the library,
+    with different fp32 summation orders -- so "an image's result does not depend on what it is batched with" (evaluate_iter, bench.py
+    --verify across world sizes) has to be CHECKED at the sizes where the thresholds sit: image 0 of BASELINE-shaped batches of 1, 3, 4
+    and 8 images (2048 x 2048 -> 800 x 800) gives bit-identical boxes, scores, labels, counts and Gaussian maps."""
+    from cvpce_amd import synthetic
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=200).to(cuda)
+    eng = det.engine()
+    imgs = [synthetic.shelf_image(g, 2048, 2048).to(cuda) for g in range(8)]
+    ref = None
+    for nb in (1, 3, 4, 8):
+        out = eng.detect(imgs[:nb], 1, 200, 0.5)
+        torch.cuda.synchronize()
+        cur = [t[0].clone() for t in out[:4]] + [out[5][0].clone()]
+        if ref is None:
+            ref = cur
+            assert int(cur[3]) > 0
+        for a, b in zip(cur, ref):
+            assert torch.equal(a, b), nb
+
+
 @pytest.mark.parametrize('batch_norm,desc_layers', [(True, [2, 3]), (False, [1, 2, 4])])
 def test_macresnet_parity(cuda, batch_norm, desc_layers):
     """Optional ResNet-50 MAC encoder (classification.py:53-85,111-121) against the fp32 oracle; state-dict keys follow

@@ -52,7 +52,7 @@ for P, G, D in cases:
                 continue
             variants += [(f'b{nq}x{mg}', 2, nq, mg, 0), (f'b{nq}x{mg}-1L', 2, nq, mg, 1)]
     for name, core, nq, mg, one in variants:
-        assert lib.cvpce_match_set_core(core, nq, mg, one) == 0
+        assert ops.match_set_core(core, nq, mg, one) == 0
         idx, dist = ops.match_topk(q, gal, 3, q_norms=qn, g_norms=gn, return_distance=True)
         idx1, dist1 = ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn, return_distance=True)      # (k = 1: the one-launch form where enabled)
         idx1b, dist1b = ops.match_topk(q, gal, 1, q_norms=qn, g_norms=gn, return_distance=True)    # ... and again on the restored state block
@@ -63,6 +63,6 @@ for P, G, D in cases:
                     and torch.equal(idx1b, ref1[0]) and torch.equal(dist1b, ref1[1]) and torch.equal(idx1, idx[:, :1]) and torch.equal(dist1, dist[:, :1]))
         us = timed(q, gal, qn, gn)
         res[name] = (round(us, 2), round(2.0 * P * G * D / us / 1e6, 1), 'same' if same else 'DIFFERENT')
-    lib.cvpce_match_set_core(0, 0, 0, 0)
+    ops.match_set_core(0, 0, 0, 0)
     bad = [k for k, v in res.items() if v[2] != 'same']
     print(f'{P} x {G} x {D}: ' + '  '.join(f'{k} {v[0]}' for k, v in res.items()) + (f'  DIFFERENT: {bad}' if bad else '  (all identical)'), flush=True)

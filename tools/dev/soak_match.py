@@ -19,7 +19,7 @@ for P, G, D in ((200, 10000, 512), (1600, 10000, 1024), (777, 3333, 256), (320, 
     gn, qn = ops.row_norms(gal), ops.row_norms(q)
     ref = None
     for core, nq, mg, one in [(1, 0, 0, 0)] + [(2, n_, m_, o_) for m_ in (1, 2) for n_ in (2, 3, 4, 5) if not (m_ == 1 and n_ == 5) for o_ in (0, 1)]:
-        assert lib.cvpce_match_set_core(core, nq, mg, one) == 0
+        assert ops.match_set_core(core, nq, mg, one) == 0
         for k in (1, 3):
             first = None
             for r in range(reps):
@@ -37,5 +37,5 @@ for P, G, D in ((200, 10000, 512), (1600, 10000, 1024), (777, 3333, 256), (320, 
                 bad += 1
     torch.cuda.synchronize()
     print(f'{P} x {G} x {D}: 15 variants x 2 k x {reps} launches, mismatches so far {bad}', flush=True)
-lib.cvpce_match_set_core(0, 0, 0, 0)
+ops.match_set_core(0, 0, 0, 0)
 print('soak_match:', 'OK' if bad == 0 else f'{bad} MISMATCHES')
