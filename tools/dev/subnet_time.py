@@ -1,4 +1,4 @@
-"""temporary: time the fused Gaussian subnet against the per-layer launches (graph-replayed)."""
+"""dev: time the fused Gaussian subnet against the per-layer launches (graph-replayed)."""
 import sys, os, math
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
