@@ -9,6 +9,7 @@ def short_name(k):
     """a rocprof kernel name without `void ` and the argument list, the template arguments kept WHOLE: round 5 cut names at 46 characters
     and merged the LIST, STRIP and plain instances of conv3x3_halo2_kernel (three different kernels) into one row."""
     k = k[5:] if k.startswith('void ') else k
+    k = k.replace('(anonymous namespace)::', '')
     depth = 0
     for i, ch in enumerate(k):
         depth += ch == '<'
