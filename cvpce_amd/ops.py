@@ -296,20 +296,17 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
     ks = splitk_factor(pc, ho, wo) if (not pool and not FORCE_GENERIC_CONV and ConvProfile.is_igemm128(pc, n * ho * wo)) else 0
     ws = None
     if ks:
-        # one fp32 workspace per (launch shape, device, STREAM): two streams running this layer at once must not share partial sums.  Captured
-        # graphs hold a workspace's address, so entries are never freed while they may be replayed; the cache is bounded by evicting the
-        # oldest entry only outside a capture, and a shape first seen DURING a capture takes the unsplit kernel (no allocation from the
-        # graph's private pool)
+        # One fp32 workspace per (launch shape, device), kept with the layer: a layer of an engine runs on ONE stream at a time (the
+        # side streams of a schedule run DIFFERENT layers), so its launches are ordered and may share the block.  The key must not
+        # depend on the stream: a hipGraph is captured on another stream than the eager first call of its geometry, and a capture that
+        # found no workspace would have to take the unsplit kernel -- another fp32 summation order, i.e. replayed results that differ
+        # from eager ones (tests/test_gpu_configs1.py).  Captured graphs hold a workspace's address, and nothing here knows which graphs
+        # are still alive: an entry is NEVER freed (tens of MB per layer and batch geometry; an engine's graph cache bounds the geometries).
         cache = pc.__dict__.setdefault('_splitk_ws', {})
-        key = (n, ho, wo, ks, x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        key = (n, ho, wo, ks, x.device)
         ws = cache.get(key)
         if ws is None:
-            if torch.cuda.is_current_stream_capturing():
-                ks = 0
-            else:
-                if len(cache) >= SPLITK_WS_MAX:
-                    cache.pop(next(iter(cache)))
-                ws = cache[key] = torch.empty(int(lib.cvpce_conv2d_splitk_workspace_bytes(n * ho * wo, pc.cout, ks)), dtype=torch.uint8, device=x.device)
+            ws = cache[key] = torch.empty(int(lib.cvpce_conv2d_splitk_workspace_bytes(n * ho * wo, pc.cout, ks)), dtype=torch.uint8, device=x.device)
     if ks:
         T.conv2d_splitk(x, pc.weight, pc.bias, residual, out, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, ho, wo, pc.k_pad, pc.cout_pad,
                         int(act), int(out_f32), int(in_up_shift), int(res_mode), ks, ws)
@@ -326,7 +323,6 @@ def conv2d(x, pc, act=0, out_f32=False, residual=None, res_mode=0, in_up_shift=0
 
 
 CONV_SPLITK = _os.environ.get('CVPCE_CONV_SPLITK', '1') != '0'   # A/B switch: split-K launches of the register-staged kernel
-SPLITK_WS_MAX = 16      # split-K workspaces kept per layer (launch shape x stream): windows of 1-8 images of a few geometries
 
 
 def splitk_factor(pc, ho, wo):
@@ -796,7 +792,8 @@ def gauss_subnet(x, convs, act):
         e1.record()
         flops = 2.0 * n * 4 * hs * ws * (9 * 64 * 32 + 9 * 32 * 32 + 9 * 32 * 16 + 16 * 16 + 16)
         prof.records.append(('gauss_subnet_kernel', flops, e0, e1))
-        prof.byte_records.append(('gauss_subnet_kernel', _nbytes(x, out), e0, e1))
+        # (not an HBM-bound stage any more: 46 MB of compulsory traffic for 83 GFLOP at 8 images -- it is filed with the conv kernels and, by
+        #  its arithmetic intensity, against the MFMA roof in the detector's per-layer table)
         prof.layer(f'gauss_subnet {2 * hs}x{2 * ws} 64->32->32->16->16->1 (2x upsampled input)', flops, _nbytes(x, out), e0, e1)
     return out
 

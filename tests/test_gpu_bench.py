@@ -99,7 +99,8 @@ def test_pipeline_line_small(cuda, tmp_path):
     assert r['lists_off']['kernel'] == 'conv3x3_halo2_kernel' and 0 < r['lists_off']['frac'] <= 1.0
     # round 5: the HBM-bound stages against the HBM roofline (algorithmic bytes, HIP-event time)
     h = r['hbm_stages']
-    assert {'gln_transform_batch_kernel', 'crop_resize_kernel', 'conv1x1_kernel', 'gauss_subnet_kernel'} <= set(h)   # (round 6: the Gaussian subnet is one launch)
+    assert {'gln_transform_batch_kernel', 'crop_resize_kernel', 'conv1x1_kernel'} <= set(h) and 'gauss_tail_kernel' not in h and 'thin3x3_kernel' not in h   # (round 6: the Gaussian subnet is ONE launch, MFMA-side)
+    assert 'gauss_subnet_kernel' in r['all_conv_kernels']
     for name, e in h.items():
         if not name.startswith('_'):
             assert e['algorithmic_gb_per_step'] > 0 and e['ms_per_step'] > 0 and 0 < e['frac_of_hbm_peak'] <= 1.0, (name, e)
