@@ -33,6 +33,7 @@ for _ in range(3):
     eng.embed_packed(crops)
 summ = ops.PROFILE.summary()
 ops.PROFILE = None
-h2 = summ['conv3x3_halo2_kernel']
-print(f"{os.path.basename(os.environ.get('CVPCE_LIB', 'libcvpce_hip.so')):44s} {dt / n * 1e3:7.2f} ms/pass  halo2 {h2['flops'] / h2['ms'] / 1e9:7.1f} TFLOP/s "
+kname = sys.argv[1] if len(sys.argv) > 1 else 'conv3x3_halo2_kernel'
+h2 = summ[kname]
+print(f"{os.path.basename(os.environ.get('CVPCE_LIB', 'libcvpce_hip.so')):44s} {dt / n * 1e3:7.2f} ms/pass  {kname} {h2['flops'] / h2['ms'] / 1e9:7.1f} TFLOP/s "
       f"({h2['ms'] / h2['launches'] * 1e3:6.0f} us/launch)  sclk {clk['sclk_mhz_median']} MHz  power {clk['power_w_median']} W", flush=True)
