@@ -38,6 +38,8 @@ CAPTURE_ON_SIGHT = 2      # a geometry is captured on its 2nd call (the 1st runs
 MAX_CAPTURE_ON_SIGHT = 16  # ... and later, up to this many sights, once captured graphs start being evicted barely used (many geometries)
 MAX_SIGHT_COUNTS = 512    # geometries whose call counts are remembered (LRU)
 USE_SIDE_BRANCHES = os.environ.get('CVPCE_SIDE_BRANCHES', '1') != '0'   # Gaussian branch beside the heads, projection shortcuts beside conv1 -> conv2
+# the fp16 storage mode checks its first batch for saturated activations once per engine and warns (CVPCE_FP16_GUARD=0 switches the check off)
+FP16_SATURATION_GUARD = os.environ.get('CVPCE_FP16_GUARD', '1') != '0'
 # opt-in: layer i of both head towers in one masked launch (568 tiles in three rounds of the persistent grid).  Built, bit-identical, NOT faster:
 # the two towers' launches already run beside each other on two streams and share the grid's second round (configs[1], same call: 2.475 ms
 # per-tower vs 2.509 ms paired; profiles/r06_rejected_experiments.md)
@@ -644,9 +646,25 @@ class GLNEngine:
         g.replay()
         return ops.clone_views(static_out)
 
+    def _saturation_guard(self, tensors):
+        """The automatic guard of the fp16 storage mode (round-5 review: fp16 stores SATURATE at +-65504 silently).  ONCE per engine, on the
+        first eager pass (the first call of a geometry is never a graph replay): the largest magnitude of C2 ... C5 and of the five FPN maps
+        of that batch (nine small reductions and one host read).  At the saturation value a warning names the remedy
+        (`set_precision('bf16')`: 8 exponent bits); `GaussianLayerNetwork.saturation_report` gives the per-stage figures.  The result is
+        kept in `self._saturation` ({'max_abs', 'saturated'})."""
+        m = float(torch.stack([t.abs().amax().float() for t in tensors]).max())
+        self._saturation = {'max_abs': m, 'saturated': m >= 65504.0}
+        if self._saturation['saturated']:
+            import warnings
+            warnings.warn('cvpce_amd GLN detector (fp16 storage, the default): an activation of the backbone / FPN reached the fp16 saturation value '
+                          '65504 on the first batch -- results of this checkpoint are clipped.  Use model.set_precision("bf16") (8 exponent bits, same '
+                          'speed) or gln(..., precision="bf16"); model.saturation_report(images) lists the stages.', RuntimeWarning, stacklevel=3)
+
     def _detect_tail(self, batch, original, resized, num_classes, detections_per_img, conf_thresh, want_intermediates):
         c2, c3, c4, c5 = self.body(batch)
         feats = self.fpn(c3, c4, c5)
+        if self.dtype == ops.F16 and FP16_SATURATION_GUARD and '_saturation' not in self.__dict__ and not torch.cuda.is_current_stream_capturing():
+            self._saturation_guard((c2, c3, c4, c5) + tuple(feats))
         # the Gaussian branch (8 small convs, proposals.py:65-107) depends on C2 and P3 only: it runs beside the heads
         gauss, gauss_done = self._beside(1, lambda: self.gaussian_branch(c2, feats[0]))
         cls, reg = self.heads_atlas(feats) if USE_HEAD_ATLAS else self.heads(feats)

@@ -285,3 +285,32 @@ def test_saturation_report(cuda):
     assert hot['saturated'] and max(v['max_abs'] for v in hot['stages'].values()) == 65504.0, hot
     det.set_precision('bf16')
     assert not det.saturation_report([img])['saturated']
+
+
+def test_fp16_saturation_guard_warns_once(cuda):
+    """Round-5 review: "fp16 stores saturate at +-65504 (`saturation_report` exists, no automatic guard)".  The engine now checks the first
+    eager batch of an fp16 engine: seeded weights stay far below the limit (no warning, the figure is kept); a checkpoint whose FPN
+    lateral weights are scaled up by 1e5 saturates and draws ONE RuntimeWarning that names the bf16 remedy; the bf16 mode never checks."""
+    import warnings
+    from cvpce_amd import synthetic
+    img = synthetic.shelf_image(0, 512, 512).to(cuda)
+    det = synthetic.synthetic_gln(seed=0, detections_per_img=50).to(cuda)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        det([img])
+    sat = det.engine()._saturation
+    assert not sat['saturated'] and 0 < sat['max_abs'] < 6e4
+    hot = synthetic.synthetic_gln(seed=0, detections_per_img=50)
+    with torch.no_grad():
+        for m in hot.backbone.fpn.inner_blocks:
+            m.weight.mul_(1e5)
+    hot = hot.to(cuda)
+    with pytest.warns(RuntimeWarning, match='set_precision'):
+        hot([img])
+    assert hot.engine()._saturation['saturated']
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        hot([img])                                    # once per engine
+        hot.set_precision('bf16')
+        hot([img])                                    # the opt-in mode has 8 exponent bits: no check
+    assert '_saturation' not in hot.engine().__dict__
