@@ -117,3 +117,44 @@ def test_resnet_body_matches_third_party_implementation(golden_dir):
     for got, ref in zip(feats.values(), fx['stages']):
         assert got.shape == ref.shape
         assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_frozen_bn_and_box_iou_match_torchvision_derived_third_party_code():
+    """Two more items of the torchvision-resident arithmetic pinned against code that is DERIVED FROM torchvision and ships in this image
+    (Hugging Face transformers): `DetrFrozenBatchNorm2d` ("copy-paste from torchvision.misc.ops with added eps before rsqrt", eps 1e-5) against
+    the oracle's `frozen_bn` (FrozenBatchNorm2d eps = 1e-5), and `transformers.loss.loss_for_object_detection.box_iou`
+    ("modified from torchvision to also return the union") against the IoU the oracle's NMS uses.  Not a fixture: both run here."""
+    pytest.importorskip('transformers')
+    from transformers.models.detr.modeling_detr import DetrFrozenBatchNorm2d
+    from transformers.loss.loss_for_object_detection import box_iou as hf_box_iou
+    g = torch.Generator().manual_seed(11)
+    c = 24
+    bn = DetrFrozenBatchNorm2d(c)
+    bn.weight.copy_(torch.rand(c, generator=g) + 0.5); bn.bias.copy_(torch.randn(c, generator=g))
+    bn.running_mean.copy_(torch.randn(c, generator=g)); bn.running_var.copy_(torch.rand(c, generator=g) * 1e-4 + 1e-6)   # (tiny variances: eps matters)
+    x = torch.randn(2, c, 5, 7, generator=g)
+    sd = {'p.weight': bn.weight, 'p.bias': bn.bias, 'p.running_mean': bn.running_mean, 'p.running_var': bn.running_var}
+    assert torch.equal(ogln.frozen_bn(x, sd, 'p'), bn(x))
+    assert ogln.FROZEN_BN_EPS == 1e-5
+    xy = torch.rand(40, 2, generator=g) * 100
+    wh = torch.rand(40, 2, generator=g) * 50 + 1
+    a = torch.cat((xy, xy + wh), 1)
+    b = a[torch.randperm(40, generator=g)] + torch.randn(40, 4, generator=g)
+    b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 0.5)
+    ref, _ = hf_box_iou(a, b)
+    from cvpce_amd import metrics
+    torch.testing.assert_close(metrics.box_iou(a, b), ref, rtol=1e-6, atol=1e-7)
+    # the oracle's greedy NMS, judged by that IoU: no two kept boxes overlap by more than the threshold, and every suppressed box does
+    # overlap an earlier-kept, higher-scoring one by more than it (strict `>`, areas without +1: torchvision's definition)
+    boxes = torch.cat((a, a + torch.randn(40, 4, generator=g) * 3))
+    boxes[:, 2:] = torch.maximum(boxes[:, 2:], boxes[:, :2] + 0.5)
+    scores = torch.rand(80, generator=g)
+    keep = ogln.nms(boxes, scores, 0.5)
+    assert bool((scores[keep][:-1] >= scores[keep][1:]).all()) and 0 < len(keep) < 80
+    iou, _ = hf_box_iou(boxes, boxes)
+    kk = iou[keep][:, keep]
+    assert float((kk - torch.eye(len(keep))).max()) <= 0.5
+    kept = set(keep.tolist())
+    for j in range(80):
+        if j not in kept:
+            assert any(float(iou[i, j]) > 0.5 and float(scores[i]) >= float(scores[j]) for i in kept), j
